@@ -1,0 +1,144 @@
+/*
+ * l2d.h -- C ABI of libl2d_hip.so: the MI355X (gfx950) backend for Live2Diff's streaming UNet step.
+ *
+ * Drop-in boundary being replaced (reference, Python):
+ *   - `stream.unet(sample, timestep, encoder_hidden_states=..., temporal_attention_mask=...,
+ *      depth_sample=..., kv_cache=..., pe_idx=..., update_idx=...)`
+ *        live2diff/pipeline_stream_animation_depth.py:456-466 (per frame), :355-365 (engine warm-up)
+ *   - the accelerator object swapped in at live2diff/utils/wrapper.py:613-626, whose contract is
+ *        live2diff/acceleration/tensorrt/engine.py:142-185 (UNet2DConditionModelDepthEngine.__call__)
+ *        and whose runtime is live2diff/acceleration/tensorrt/utilities.py:247-294 (Engine.infer).
+ * The reference has no FFI of its own (it is 100 % Python driving PyTorch / TensorRT); this header is
+ * what a ctypes binding on the reference side binds instead of `Engine.infer`.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers (HBM) unless stated; sizes are ints; no torch types.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream). Nothing here synchronises.
+ *   - every function returns 0 on success, a negative L2D_E* code otherwise; l2d_last_error() gives text.
+ *   - activations are channels-last fp16: a tensor "[B,T,C]" is B*T rows of C contiguous halfs.
+ *   - KV caches use the reference interchange layout [N,2,T,L,C] fp16
+ *        (live2diff/animatediff/models/stream_motion_module.py:57-77).
+ *
+ * A UNet step is a static *plan*: an array of l2d_op records (one per kernel launch) that the host
+ * builds once per (H,W,N,L) and that l2d_run_ops()/l2d_graph_* replay every frame.
+ */
+#ifndef L2D_H
+#define L2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2D_ABI_VERSION 1
+
+enum {
+    L2D_OK = 0,
+    L2D_EINVAL = -1,   /* bad argument / unsupported shape */
+    L2D_ELAUNCH = -2,  /* HIP launch or runtime error */
+    L2D_ENODEV = -3,   /* no gfx950 device */
+};
+
+/* op kinds ---------------------------------------------------------------------------------------
+ * Field meaning per kind (p = pointers, i = ints, f = floats); unused fields must be 0.
+ *
+ * L2D_OP_IGEMM   implicit GEMM on MFMA: linear / 1x1 conv / 3x3 conv (stride 1|2, optional nearest-2x
+ *                upsample folded into the gather, optional channel-concat of two inputs), fused epilogue.
+ *                out[m][n] = epi( sum_k X[m][k] * W[n][k] )        (reference: nn.Linear / InflatedConv3d,
+ *                resnet.py:57-65,112,141; attention.py:62,89; motion_module.py:182,207)
+ *   p0 x1 [B,Hin,Win,C1] half   p1 x2 [.., C2] half or 0        p2 w packed [Nout][taps*CinP] half
+ *   p3 bias[Nout] float or 0    p4 rowbias [*, ldrb] float or 0 p5 residual [M][ldr] half or 0
+ *   p6 out [M][ldo] half
+ *   i0 taps(1|9) i1 C1 i2 C2 i3 ldx1 i4 ldx2 i5 CinP i6 B i7 Hin i8 Win i9 Hout i10 Wout i11 stride
+ *   i12 ups(0|1) i13 M i14 Nout i15 ldo i16 ldr i17 ldrb i18 rows_per_bias i19 epi (0 none, 1 GEGLU, 2 SiLU)
+ *   i20 batch (grid.z) ; l0..l3 = per-batch element strides of x1, w, out, residual
+ *
+ * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
+ *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)
+ *   p0 x1 p1 x2|0 p2 partial[B][nchunk][G][2] float  (apply: p3 gamma half, p4 beta half, p5 out half)
+ *   i0 B i1 T i2 C1 i3 C2 i4 ld1 i5 ld2 i6 G i7 nchunk i8 silu  f0 eps
+ *
+ * L2D_OP_LAYERNORM  p0 x [rows][ld] p1 gamma p2 beta p3 out [rows][C] ; i0 rows i1 C i2 ldx i3 ldo; f0 eps
+ *
+ * L2D_OP_FLASH_ATTN  softmax(QK^T/sqrt(d))V on MFMA (spatial self / text cross attention;
+ *                reference call sites attention.py:243,250-255)
+ *   p0 q [B][Tq][ldq] p1 k [B][Tk][ldk] p2 vt [B][H*d][ldvt] (V transposed) p3 out [B][Tq][ldo]
+ *   i0 B i1 H i2 d i3 Tq i4 Tk i5 ldq i6 ldk i7 ldvt i8 ldo ; l0 q batch stride l1 k l2 vt l3 out
+ *
+ * L2D_OP_TATTN_STREAM  fused streaming temporal attention with multi-timestep KV-cache
+ *                (reference stream_motion_module.py:99-213)
+ *   p0 qkv [N*T][3C] half p1 cache [N,2,T,L,C] half (in-place) p2 q_pe p3 k_pe p4 v_pe [maxlen][C] half
+ *   p5 pe_idx [N][L] int64 p6 update_idx [N] int64 p7 bias [N][L] half p8 out [N*T][C] half
+ *   i0 N i1 T i2 C i3 L i4 H i5 variant (0 auto; 1 register-resident, 2/3 chunked CH=8/4: tuning knob)
+ *
+ * L2D_OP_TATTN_WARMUP  bidirectional warm-up temporal attention + cache fill
+ *                (reference motion_module.py:469-530)
+ *   p0 qkv [F*T][3C] p1 cache_row [2,T,L,C] p2 q_pe p3 k_pe p4 v_pe p8 out [F*T][C]
+ *   i0 F i1 T i2 C i3 L i4 H
+ *
+ * L2D_OP_SKINNY_LINEAR  out[m][n] = act( sum_k A[m][k] W[n][k] + b[n] ), m < 8 (time embedding path,
+ *                reference unet_depth_streaming.py:499-505, resnet.py:238)
+ *   p0 A half [M][K] p1 W half [Nout][K] p2 bias float p3 out (half or float) ; i0 M i1 K i2 Nout
+ *   i3 silu_out i4 out_is_float i5 ldo
+ * L2D_OP_TIMESTEP_EMBED  p0 timesteps (int64 [N]) p1 out half [N][dim]; i0 N i1 dim
+ * L2D_OP_NCHW_TO_NHWC  p0 in half [B][C][HW] p1 out half [B][HW][Cpad]; i0 B i1 C i2 HW i3 Cpad
+ * L2D_OP_NHWC_TO_NCHW  p0 in half [B][HW][ld] p1 out half [B][C][HW]; i0 B i1 C i2 HW i3 ld
+ * L2D_OP_LCM_STEP   x0 = c_out*(x - beta*eps)/alpha + c_skip*x  (reference pipeline :387-401)
+ *   p0 x p1 eps p2 scal float [N][4]={alpha,beta,c_skip,c_out} p3 x0 ; i0 N i1 per_sample_elems
+ * L2D_OP_COPY       p0 src p1 dst ; l0 bytes   (device-to-device, on the stream)
+ */
+enum {
+    L2D_OP_IGEMM = 1,
+    L2D_OP_GN_STATS = 2,
+    L2D_OP_GN_APPLY = 3,
+    L2D_OP_LAYERNORM = 4,
+    L2D_OP_FLASH_ATTN = 5,
+    L2D_OP_TATTN_STREAM = 6,
+    L2D_OP_TATTN_WARMUP = 7,
+    L2D_OP_SKINNY_LINEAR = 8,
+    L2D_OP_TIMESTEP_EMBED = 9,
+    L2D_OP_NCHW_TO_NHWC = 10,
+    L2D_OP_NHWC_TO_NCHW = 11,
+    L2D_OP_LCM_STEP = 12,
+    L2D_OP_COPY = 13,
+};
+
+typedef struct l2d_op {
+    int32_t kind;
+    int32_t tag;          /* free for the host (plan index / layer id); echoed in error messages */
+    void *p[10];
+    int32_t i[24];
+    int64_t l[4];
+    float f[4];
+} l2d_op;
+
+/* library / device ------------------------------------------------------------------------------ */
+int l2d_abi_version(void);
+const char *l2d_last_error(void);
+/* 0 if the current HIP device is a gfx950 part; fills name (<= 63 chars) when non-NULL. */
+int l2d_device_check(char *name, int name_len);
+
+/* Validate-only mode: when on, l2d_run_ops checks every op's arguments exactly as a real launch would and
+ * returns without touching the device (used by the CPU test-suite to check whole plans). */
+int l2d_set_dry_run(int on);
+
+/* execution ------------------------------------------------------------------------------------- */
+/* Launch ops[0..n) in order on `stream`. */
+int l2d_run_ops(const l2d_op *ops, int n, void *stream);
+/* Capture ops[0..n) into a hipGraph on `stream` (stream capture) and instantiate it. */
+int l2d_graph_create(const l2d_op *ops, int n, void *stream, void **graph_out);
+int l2d_graph_launch(void *graph, void *stream);
+int l2d_graph_destroy(void *graph);
+
+/* timing helper for bench.py: hipEvent pair around `reps` runs of the ops on `stream`; returns ms. */
+int l2d_time_ops(const l2d_op *ops, int n, void *stream, int reps, float *ms_out);
+
+/* HBM copy microbenchmark (device-to-device float4 copy kernel), used to state the measured HBM peak
+ * next to the datasheet number: copies `bytes` from src to dst `reps` times, returns GB/s (read+write). */
+int l2d_copy_bench(const void *src, void *dst, int64_t bytes, int reps, void *stream, float *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L2D_H */

@@ -1,0 +1,60 @@
+// Shared device/host helpers for the gfx950 kernels of libl2d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/l2d.h"
+
+typedef _Float16 h16;
+typedef h16 __attribute__((ext_vector_type(2))) h16x2;
+typedef h16 __attribute__((ext_vector_type(4))) h16x4;
+typedef h16 __attribute__((ext_vector_type(8))) h16x8;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+#define L2D_WAVE 64
+
+// host-side error plumbing (capi.cpp)
+void l2d_set_error(const char *fmt, ...);
+int l2d_check_launch(const char *what, int tag);
+// validate-only mode (l2d_set_dry_run): launchers return right after argument validation
+extern int l2d_g_dry_run;
+#define L2D_DRY_RETURN() do { if (l2d_g_dry_run) return L2D_OK; } while (0)
+
+// per-kernel launchers (one translation unit each); all return L2D_OK / L2D_E*
+int l2d_launch_igemm(const l2d_op *op, hipStream_t s);
+int l2d_launch_gn_stats(const l2d_op *op, hipStream_t s);
+int l2d_launch_gn_apply(const l2d_op *op, hipStream_t s);
+int l2d_launch_layernorm(const l2d_op *op, hipStream_t s);
+int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s);
+int l2d_launch_tattn_stream(const l2d_op *op, hipStream_t s);
+int l2d_launch_tattn_warmup(const l2d_op *op, hipStream_t s);
+int l2d_launch_skinny_linear(const l2d_op *op, hipStream_t s);
+int l2d_launch_timestep_embed(const l2d_op *op, hipStream_t s);
+int l2d_launch_nchw_to_nhwc(const l2d_op *op, hipStream_t s);
+int l2d_launch_nhwc_to_nchw(const l2d_op *op, hipStream_t s);
+int l2d_launch_lcm_step(const l2d_op *op, hipStream_t s);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float l2d_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, matching torch.nn.functional.gelu default used by diffusers' GEGLU
+__device__ __forceinline__ float l2d_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ h16x8 l2d_ld8(const h16 *p) { return *reinterpret_cast<const h16x8 *>(p); }
+__device__ __forceinline__ void l2d_st8(h16 *p, h16x8 v) { *reinterpret_cast<h16x8 *>(p) = v; }
+__device__ __forceinline__ h16x8 l2d_zero8() {
+    h16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (h16)0.0f;
+    return z;
+}
+__device__ __forceinline__ float l2d_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float l2d_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif

@@ -1,0 +1,256 @@
+// Flash attention on MFMA for gfx950: spatial self-attention (T x T, T up to 9216) and text
+// cross-attention (T x 77) of the SD-1.5 transformer blocks.  Replaces the SDPA call inside diffusers'
+// `Attention` that the reference reaches from attention.py:243 (attn1) and :250-255 (attn2).
+//
+//   O[q][:] = softmax_k( Q[q].K[k] / sqrt(d) ) . V[k][:]        per (batch b, head h), no mask
+//
+// "Swapped" formulation so that the probabilities never leave registers:
+//   S^T = K.Q^T      A operand = K tile rows (keys, from LDS), B operand = Q (held in registers)
+//   O^T += V^T.P^T   A operand = V^T tile rows (head-dim, from LDS), B operand = P^T
+// With v_mfma_f32_16x16x32_f16 the S^T accumulator puts, in lane (q = lane&15, g = lane>>4), the keys
+// {16*ks + 4g + r}; that is exactly a valid K-slot assignment for the B operand of the second MFMA
+// (any permutation of the contraction index is legal as long as A and B agree), so P^T is built
+// lane-locally with 8 cvt and zero cross-lane traffic; the matching V^T A-fragment is two 8-byte LDS
+// reads.  V arrives already transposed ([B][H*d][Tk]): the projection GEMM that produces V is simply
+// issued with its operand roles swapped (see unet_hip.py), so no transpose pass exists anywhere.
+// Softmax row statistics need only 2 cross-lane steps (xor 16, 32).
+//
+// Block = 4 waves x 32 query rows = 128 queries of one (b, h); K / V^T tiles of 64 keys are staged
+// through LDS (register prefetch of tile t+1 during compute of tile t; double-buffered when it fits).
+// LDS row strides are padded to the conflict-free residues found by simulating the gfx950 lane-group
+// tables: K rows (ds_read_b128) stride = DQK+16 halfs, V^T rows (ds_read_b64) stride = 72 halfs.
+#include "common.h"
+
+struct FAArgs {
+    const h16 *q, *k, *vt;
+    h16 *out;
+    int B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo;
+    long long sq, sk, svt, so;
+};
+
+template <int D>
+struct FACfg {
+    static constexpr int DQK = ((D + 31) / 32) * 32;  // contraction length of QK^T, zero padded
+    static constexpr int KK = DQK / 32;
+    static constexpr int D16 = (D + 15) / 16;          // 16-row blocks of O^T
+    static constexpr int KROW = DQK + 16;              // halfs
+    static constexpr int VROW = 72;                    // halfs (64 keys + pad)
+    static constexpr int KCH = (64 * (DQK / 8)) / 256;            // K staging chunks per thread
+    static constexpr int VTOT = D16 * 16 * 8;                     // V^T staging chunks per tile
+    static constexpr int VCH = (VTOT + 255) / 256;
+    static constexpr int TILE_HALFS = 64 * KROW + D16 * 16 * VROW;
+    static constexpr int NBUF = (TILE_HALFS * 2 * 2 <= 65536) ? 2 : 1;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
+    using Cf = FACfg<D>;
+    constexpr int DQK = Cf::DQK, KK = Cf::KK, D16 = Cf::D16, KROW = Cf::KROW, VROW = Cf::VROW;
+    constexpr int KCH = Cf::KCH, VCH = Cf::VCH, NBUF = Cf::NBUF;
+    __shared__ __attribute__((aligned(16))) h16 smem[NBUF * Cf::TILE_HALFS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const h16 *qp = a.q + (long long)b * a.sq + h * D;
+    const h16 *kp = a.k + (long long)b * a.sk + h * D;
+    const h16 *vp = a.vt + (long long)b * a.svt + (long long)h * D * a.ldvt;
+    h16 *op = a.out + (long long)b * a.so + h * D;
+
+    // Q fragments (B operand): lane (j=li, g=lg) holds Q[q0 + qs*16 + j][kk*32 + 8g .. +7]
+    h16x8 qf[2][KK];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            int qr = q0 + qs * 16 + li, dc = kk * 32 + lg * 8;
+            qf[qs][kk] = (qr < a.Tq && dc < D) ? l2d_ld8(qp + (long long)qr * a.ldq + dc) : l2d_zero8();
+        }
+
+    h16x8 kreg[KCH], vreg[VCH];
+    auto load_tiles = [&](int key0) {
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            int id = tid + 256 * j;
+            int r = id / (DQK / 8), c8 = id - r * (DQK / 8);
+            int key = key0 + r;
+            kreg[j] = (key < a.Tk && c8 * 8 < D) ? l2d_ld8(kp + (long long)key * a.ldk + c8 * 8) : l2d_zero8();
+        }
+#pragma unroll
+        for (int j = 0; j < VCH; ++j) {
+            int id = tid + 256 * j;
+            int dd = id >> 3, c = id & 7;
+            int key = key0 + c * 8;
+            h16x8 v = l2d_zero8();
+            if (id < Cf::VTOT && dd < D && key < a.Tk) {
+                v = l2d_ld8(vp + (long long)dd * a.ldvt + key);
+                if (key + 8 > a.Tk) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key + e >= a.Tk) v[e] = (h16)0.0f;   // padding columns may hold anything
+                }
+            }
+            vreg[j] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        h16 *Ks = smem + buf * Cf::TILE_HALFS;
+        h16 *Vs = Ks + 64 * KROW;
+#pragma unroll
+        for (int j = 0; j < KCH; ++j) {
+            int id = tid + 256 * j;
+            int r = id / (DQK / 8), c8 = id - r * (DQK / 8);
+            l2d_st8(Ks + r * KROW + c8 * 8, kreg[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VCH; ++j) {
+            int id = tid + 256 * j;
+            if (id < Cf::VTOT) l2d_st8(Vs + (id >> 3) * VROW + (id & 7) * 8, vreg[j]);
+        }
+    };
+
+    f32x4 oacc[D16][2];
+#pragma unroll
+    for (int ds = 0; ds < D16; ++ds)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) oacc[ds][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-1.0e30f, -1.0e30f}, lrow[2] = {0.f, 0.f};
+    const float c2e = rsqrtf((float)D) * 1.4426950408889634f;   // 1/sqrt(d) * log2(e)
+
+    const int nt = (a.Tk + 63) / 64;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) load_tiles((kt + 1) * 64);
+        const h16 *Ks = smem + cur * Cf::TILE_HALFS;
+        const h16 *Vs = Ks + 64 * KROW;
+
+        f32x4 sacc[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) sacc[ks][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                h16x8 kf = l2d_ld8(Ks + (ks * 16 + li) * KROW + kk * 32 + lg * 8);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs)
+                    sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][kk], sacc[ks][qs], 0, 0, 0);
+            }
+        // scale to the exp2 domain, mask keys beyond Tk (last tile only)
+        const bool tail = (kt + 1) * 64 > a.Tk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = sacc[ks][qs][r] * c2e;
+                    if (tail && (kt * 64 + ks * 16 + lg * 4 + r) >= a.Tk) v = -1.0e30f;
+                    sacc[ks][qs][r] = v;
+                }
+        h16x8 pf[2][2];   // [c2][qs]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = sacc[0][qs][0];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[ks][qs][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrow[qs], mx);
+            const float alpha = exp2f(mrow[qs] - mnew);
+            mrow[qs] = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = exp2f(sacc[ks][qs][r] - mnew);
+                    psum += pv;
+                    pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
+                }
+            lrow[qs] = lrow[qs] * alpha + psum;
+#pragma unroll
+            for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int ds = 0; ds < D16; ++ds) {
+                const h16 *vr = Vs + (ds * 16 + li) * VROW + c2 * 32 + lg * 4;
+                h16x4 lo = *reinterpret_cast<const h16x4 *>(vr);
+                h16x4 hi = *reinterpret_cast<const h16x4 *>(vr + 16);
+                h16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs)
+                    oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+            }
+        if (NBUF == 2) {
+            if (kt + 1 < nt) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (kt + 1 < nt) store_tiles(0);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = lrow[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qs * 16 + li;
+        if (qr >= a.Tq) continue;
+#pragma unroll
+        for (int ds = 0; ds < D16; ++ds) {
+            int dc = ds * 16 + lg * 4;
+            if (dc >= D) continue;
+            h16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (h16)(oacc[ds][qs][r] * inv);
+            *reinterpret_cast<h16x4 *>(op + (long long)qr * a.ldo + dc) = o;
+        }
+    }
+}
+
+template <int D>
+static void launch_fa(const FAArgs &a, hipStream_t s) {
+    dim3 grid((a.Tq + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, s, a);
+}
+
+int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
+    FAArgs a;
+    a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
+    a.B = op->i[0]; a.H = op->i[1]; a.d = op->i[2]; a.Tq = op->i[3]; a.Tk = op->i[4];
+    a.ldq = op->i[5]; a.ldk = op->i[6]; a.ldvt = op->i[7]; a.ldo = op->i[8];
+    a.sq = op->l[0]; a.sk = op->l[1]; a.svt = op->l[2]; a.so = op->l[3];
+    if (!a.q || !a.k || !a.vt || !a.out || a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0 || (a.ldq % 8) || (a.ldk % 8) ||
+        (a.ldvt % 8) || (a.ldo % 4) || a.ldvt < ((a.Tk + 7) / 8) * 8) {
+        l2d_set_error("flash_attn(tag %d): invalid arguments (B=%d H=%d d=%d Tq=%d Tk=%d ldvt=%d)", op->tag, a.B, a.H, a.d,
+                      a.Tq, a.Tk, a.ldvt);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    switch (a.d) {
+        case 8: launch_fa<8>(a, s); break;
+        case 16: launch_fa<16>(a, s); break;
+        case 32: launch_fa<32>(a, s); break;
+        case 40: launch_fa<40>(a, s); break;
+        case 80: launch_fa<80>(a, s); break;
+        case 160: launch_fa<160>(a, s); break;
+        default:
+            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,80,160)", op->tag, a.d);
+            return L2D_EINVAL;
+    }
+    return l2d_check_launch("flash_attn", op->tag);
+}

@@ -1,0 +1,196 @@
+// Small latency-bound kernels on the UNet boundary (gfx950):
+//   timestep_embed : diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)`
+//                    (call site reference unet_depth_streaming.py:102,499)
+//   skinny_linear  : nn.Linear for <= 8 rows (time embedding MLP + every resnet's time_emb_proj,
+//                    reference unet_depth_streaming.py:505, resnet.py:238): one wave per output column,
+//                    weights streamed once with 16-byte loads, wave-shuffle reduction
+//   nchw<->nhwc    : the reference interface is NCFHW (f=1); the backend is channels-last end to end,
+//                    so the only two layout conversions of the whole step are on the 4-channel latents
+//   lcm_step       : scheduler_step_batch (reference pipeline_stream_animation_depth.py:387-401)
+//   copy_bench     : float4 device copy used to quote the measured HBM peak next to the roofline
+#include "common.h"
+
+__global__ void timestep_embed_kernel(const long long *__restrict__ t, h16 *__restrict__ out, int N, int dim) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int half = dim / 2;
+    if (idx >= N * half) return;
+    int n = idx / half, i = idx - n * half;
+    float freq = __expf(-9.210340371976184f * (float)i / (float)half);   // ln(10000)
+    float ang = (float)t[n] * freq;
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    out[(long long)n * dim + i] = (h16)cs;          // flip_sin_to_cos: [cos | sin]
+    out[(long long)n * dim + half + i] = (h16)sn;
+}
+
+int l2d_launch_timestep_embed(const l2d_op *op, hipStream_t s) {
+    int N = op->i[0], dim = op->i[1];
+    if (!op->p[0] || !op->p[1] || N <= 0 || dim <= 0 || (dim & 1)) {
+        l2d_set_error("timestep_embed(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    int total = N * dim / 2;
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const long long *)op->p[0],
+                       (h16 *)op->p[1], N, dim);
+    return l2d_check_launch("timestep_embed", op->tag);
+}
+
+// out[m][n] = act( sum_k A[m][k] W[n][k] + b[n] ), M <= 8.  One wave per column n.
+template <int MM>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const h16 *__restrict__ A, const h16 *__restrict__ W,
+                                                            const float *__restrict__ bias, void *__restrict__ out, int K,
+                                                            int Nout, int silu_out, int out_is_float, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= Nout) return;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const int nvc = K / 8;
+    for (int vc = lane; vc < nvc; vc += 64) {
+        h16x8 w = l2d_ld8(W + (long long)n * K + vc * 8);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            h16x8 x = l2d_ld8(A + (long long)m * K + vc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[m] += (float)w[e] * (float)x[e];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        float v = l2d_wave_sum(acc[m]);
+        if (lane == 0) {
+            if (bias) v += bias[n];
+            if (silu_out) v = l2d_silu(v);
+            if (out_is_float) ((float *)out)[(long long)m * ldo + n] = v;
+            else ((h16 *)out)[(long long)m * ldo + n] = (h16)v;
+        }
+    }
+}
+
+int l2d_launch_skinny_linear(const l2d_op *op, hipStream_t s) {
+    const h16 *A = (const h16 *)op->p[0], *W = (const h16 *)op->p[1];
+    const float *bias = (const float *)op->p[2];
+    void *out = op->p[3];
+    int M = op->i[0], K = op->i[1], Nout = op->i[2], silu = op->i[3], isf = op->i[4], ldo = op->i[5];
+    if (!A || !W || !out || M <= 0 || M > 8 || K <= 0 || (K % 8) || Nout <= 0 || ldo < Nout) {
+        l2d_set_error("skinny_linear(tag %d): invalid arguments (M=%d K=%d N=%d)", op->tag, M, K, Nout);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    dim3 grid((Nout + 3) / 4), block(256);
+#define L2D_SK(MMV) \
+    case MMV: hipLaunchKernelGGL((skinny_linear_kernel<MMV>), grid, block, 0, s, A, W, bias, out, K, Nout, silu, isf, ldo); break;
+    switch (M) {
+        L2D_SK(1) L2D_SK(2) L2D_SK(3) L2D_SK(4) L2D_SK(5) L2D_SK(6) L2D_SK(7) L2D_SK(8)
+    }
+#undef L2D_SK
+    return l2d_check_launch("skinny_linear", op->tag);
+}
+
+__global__ void nchw_to_nhwc_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int Cpad) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * HW * Cpad;
+    if (idx >= total) return;
+    int c = (int)(idx % Cpad);
+    long long pix = idx / Cpad;
+    int b = (int)(pix / HW);
+    int hw = (int)(pix - (long long)b * HW);
+    out[idx] = (c < C) ? in[((long long)b * C + c) * HW + hw] : (h16)0.0f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int ld) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * C * HW;
+    if (idx >= total) return;
+    int hw = (int)(idx % HW);
+    long long bc = idx / HW;
+    int c = (int)(bc % C);
+    int b = (int)(bc / C);
+    out[idx] = in[((long long)b * HW + hw) * ld + c];
+}
+
+int l2d_launch_nchw_to_nhwc(const l2d_op *op, hipStream_t s) {
+    int B = op->i[0], C = op->i[1], HW = op->i[2], Cpad = op->i[3];
+    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) {
+        l2d_set_error("nchw_to_nhwc(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    long long total = (long long)B * HW * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0],
+                       (h16 *)op->p[1], B, C, HW, Cpad);
+    return l2d_check_launch("nchw_to_nhwc", op->tag);
+}
+
+int l2d_launch_nhwc_to_nchw(const l2d_op *op, hipStream_t s) {
+    int B = op->i[0], C = op->i[1], HW = op->i[2], ld = op->i[3];
+    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || ld < C) {
+        l2d_set_error("nhwc_to_nchw(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    long long total = (long long)B * C * HW;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0],
+                       (h16 *)op->p[1], B, C, HW, ld);
+    return l2d_check_launch("nhwc_to_nchw", op->tag);
+}
+
+// x0 = c_out * (x - beta*eps)/alpha + c_skip * x ; scal[n] = {alpha, beta, c_skip, c_out}
+__global__ void lcm_step_kernel(const h16 *__restrict__ x, const h16 *__restrict__ eps, const float *__restrict__ scal,
+                                h16 *__restrict__ x0, int N, int per) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * per) return;
+    int n = (int)(idx / per);
+    float al = scal[n * 4 + 0], be = scal[n * 4 + 1], cs = scal[n * 4 + 2], co = scal[n * 4 + 3];
+    float xv = (float)x[idx], ev = (float)eps[idx];
+    // same fp16 rounding points as the reference's half-precision tensor expression (:395-396)
+    h16 f = (h16)((float)(h16)(xv - (float)(h16)(be * ev)) / al);
+    x0[idx] = (h16)((float)(h16)(co * (float)f) + (float)(h16)(cs * xv));
+}
+
+int l2d_launch_lcm_step(const l2d_op *op, hipStream_t s) {
+    int N = op->i[0], per = op->i[1];
+    if (!op->p[0] || !op->p[1] || !op->p[2] || !op->p[3] || N <= 0 || per <= 0) {
+        l2d_set_error("lcm_step(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    long long total = (long long)N * per;
+    hipLaunchKernelGGL(lcm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0],
+                       (const h16 *)op->p[1], (const float *)op->p[2], (h16 *)op->p[3], N, per);
+    return l2d_check_launch("lcm_step", op->tag);
+}
+
+// ------------------------------------------------------------------------------------------- HBM copy probe
+__global__ __launch_bounds__(256) void copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, long long n16) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int l2d_copy_bench(const void *src, void *dst, int64_t bytes, int reps, void *stream, float *gbps_out) {
+    if (!src || !dst || bytes < 16 || reps <= 0 || !gbps_out) {
+        l2d_set_error("copy_bench: invalid arguments");
+        return L2D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    long long n16 = bytes / 16;
+    int grid = 256 * 8;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (f32x4 *)dst, n16);
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (f32x4 *)dst, n16);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbps_out = (float)(2.0 * (double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9);
+    return l2d_check_launch("copy_bench", 0);
+}

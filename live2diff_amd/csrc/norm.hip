@@ -1,0 +1,210 @@
+// GroupNorm (+SiLU) and LayerNorm for channels-last fp16 activations on gfx950.  HBM-bound:
+// 16-byte vector loads, fp32 statistics, wave-shuffle reductions, no intermediate layout copies.
+//
+// GroupNorm replaces nn.GroupNorm / InflatedGroupNorm (+ F.silu) of the reference (resnet.py:68-76,
+// 232-233,243,249; attention.py:57,102; motion_module.py:181,273; unet_depth_streaming.py:620-621).
+// It reads up to two inputs as one virtual channel-concat [x1 | x2], so the skip-connection torch.cat
+// of the up blocks (unet_blocks_streaming.py:683,814) is never materialised.
+//   pass 1 (gn_stats): per-(b, pixel-chunk) partial sum / sum-of-squares for each of the G groups
+//   pass 2 (gn_apply): deterministic reduction of the partials, then y = (x-mean)*rstd*gamma+beta (-> SiLU)
+// LayerNorm replaces nn.LayerNorm (attention.py:182,199,205; motion_module.py:355,361): one wave per row.
+#include "common.h"
+
+struct GNArgs {
+    const h16 *x1, *x2;
+    float *partial;
+    const h16 *gamma, *beta;
+    h16 *out;
+    int B, T, C1, C2, ld1, ld2, G, nchunk, silu;
+    float eps;
+};
+
+// thread -> (pixel row within the pass, 8-channel vector column); returns false if idle
+__device__ __forceinline__ h16x8 gn_load(const GNArgs &a, long long pix, int vc) {
+    int c = vc * 8;
+    const h16 *src = (c < a.C1) ? a.x1 + pix * a.ld1 + c : a.x2 + pix * a.ld2 + (c - a.C1);
+    return l2d_ld8(src);
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
+    __shared__ float s_sum[64], s_sq[64];
+    const int tid = threadIdx.x;
+    const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (a.T + a.nchunk - 1) / a.nchunk;
+    const int t0 = chunk * per, t1 = min(a.T, t0 + per);
+    if (tid < 64) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+    __syncthreads();
+    const int cols = min(nvc, 256), PR = 256 / cols;
+    const int prow = tid / cols, vcl = tid - prow * cols;
+    for (int cb = 0; cb < nvc; cb += cols) {
+        int vc = cb + vcl;
+        if (prow >= PR || vc >= nvc) continue;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int t = t0 + prow; t < t1; t += PR) {
+            h16x8 v = gn_load(a, (long long)b * a.T + t, vc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        }
+        // fold the 8 channels into their groups (runs of equal group id), then LDS atomics
+        int g_prev = (vc * 8) / cpg;
+        float rs = 0.f, rq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int g = (vc * 8 + e) / cpg;
+            if (g != g_prev) { atomicAdd(&s_sum[g_prev], rs); atomicAdd(&s_sq[g_prev], rq); rs = 0.f; rq = 0.f; g_prev = g; }
+            rs += s[e]; rq += q[e];
+        }
+        atomicAdd(&s_sum[g_prev], rs);
+        atomicAdd(&s_sq[g_prev], rq);
+    }
+    __syncthreads();
+    if (tid < a.G) {
+        float *dst = a.partial + (((long long)b * a.nchunk + chunk) * a.G + tid) * 2;
+        dst[0] = s_sum[tid];
+        dst[1] = s_sq[tid];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_block) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int tid = threadIdx.x;
+    const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
+    const int b = blockIdx.y;
+    if (tid < a.G) {
+        float s = 0.f, q = 0.f;
+        const float *src = a.partial + ((long long)b * a.nchunk * a.G + tid) * 2;
+        for (int ch = 0; ch < a.nchunk; ++ch) { s += src[0]; q += src[1]; src += a.G * 2; }
+        float inv = 1.0f / ((float)a.T * (float)cpg);
+        float mean = s * inv;
+        float var = fmaxf(q * inv - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + a.eps);
+    }
+    __syncthreads();
+    const int t0 = blockIdx.x * pix_per_block, t1 = min(a.T, t0 + pix_per_block);
+    const int cols = min(nvc, 256), PR = 256 / cols;
+    const int prow = tid / cols, vcl = tid - prow * cols;
+    for (int cb = 0; cb < nvc; cb += cols) {
+        int vc = cb + vcl;
+        if (prow >= PR || vc >= nvc) continue;
+        float sc[8], sh[8];
+        h16x8 gm = l2d_ld8(a.gamma + vc * 8), bt = l2d_ld8(a.beta + vc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int g = (vc * 8 + e) / cpg;
+            sc[e] = s_rstd[g] * (float)gm[e];
+            sh[e] = (float)bt[e] - s_mean[g] * sc[e];
+        }
+        for (int t = t0 + prow; t < t1; t += PR) {
+            long long pix = (long long)b * a.T + t;
+            h16x8 v = gn_load(a, pix, vc), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = (float)v[e] * sc[e] + sh[e];
+                if (a.silu) y = l2d_silu(y);
+                o[e] = (h16)y;
+            }
+            l2d_st8(a.out + pix * C + vc * 8, o);
+        }
+    }
+}
+
+static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
+    a.x1 = (const h16 *)op->p[0]; a.x2 = (const h16 *)op->p[1]; a.partial = (float *)op->p[2];
+    a.gamma = (const h16 *)op->p[3]; a.beta = (const h16 *)op->p[4]; a.out = (h16 *)op->p[5];
+    a.B = op->i[0]; a.T = op->i[1]; a.C1 = op->i[2]; a.C2 = op->i[3]; a.ld1 = op->i[4]; a.ld2 = op->i[5];
+    a.G = op->i[6]; a.nchunk = op->i[7]; a.silu = op->i[8]; a.eps = op->f[0];
+    int C = a.C1 + a.C2;
+    if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 64 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
+        (a.C2 > 0 && !a.x2) || a.nchunk <= 0 || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
+        (apply && (!a.gamma || !a.beta || !a.out))) {
+        l2d_set_error("groupnorm(tag %d): invalid arguments (B=%d T=%d C1=%d C2=%d G=%d nchunk=%d)", op->tag, a.B, a.T,
+                      a.C1, a.C2, a.G, a.nchunk);
+        return L2D_EINVAL;
+    }
+    return L2D_OK;
+}
+
+int l2d_launch_gn_stats(const l2d_op *op, hipStream_t s) {
+    GNArgs a;
+    int rc = gn_args(op, a, false);
+    if (rc) return rc;
+    L2D_DRY_RETURN();
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunk, a.B), dim3(256), 0, s, a);
+    return l2d_check_launch("gn_stats", op->tag);
+}
+
+int l2d_launch_gn_apply(const l2d_op *op, hipStream_t s) {
+    GNArgs a;
+    int rc = gn_args(op, a, true);
+    if (rc) return rc;
+    L2D_DRY_RETURN();
+    int C = a.C1 + a.C2;
+    // ~64 KB of activations per block, at least one pass of pixel rows
+    int ppb = (32768 + C - 1) / C;
+    int pr = 256 / ((C / 8) < 256 ? (C / 8) : 256);
+    if (ppb < pr) ppb = pr;
+    if (ppb > a.T) ppb = a.T;
+    int nb = (a.T + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, a.B), dim3(256), 0, s, a, ppb);
+    return l2d_check_launch("gn_apply", op->tag);
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+__global__ __launch_bounds__(256) void layernorm_kernel(const h16 *__restrict__ x, const h16 *__restrict__ gamma,
+                                                        const h16 *__restrict__ beta, h16 *__restrict__ out, int rows,
+                                                        int C, int ldx, int ldo, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvc = C / 8;
+    constexpr int MAXV = 4;  // C <= 2048
+    h16x8 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        int vc = lane + 64 * j;
+        if (vc < nvc) {
+            v[j] = l2d_ld8(x + (long long)row * ldx + vc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[j][e];
+        }
+    }
+    float mean = l2d_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        int vc = lane + 64 * j;
+        if (vc < nvc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float d = (float)v[j][e] - mean; q += d * d; }
+        }
+    }
+    float rstd = rsqrtf(l2d_wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        int vc = lane + 64 * j;
+        if (vc < nvc) {
+            h16x8 gm = l2d_ld8(gamma + vc * 8), bt = l2d_ld8(beta + vc * 8), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[j][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+            l2d_st8(out + (long long)row * ldo + vc * 8, o);
+        }
+    }
+}
+
+int l2d_launch_layernorm(const l2d_op *op, hipStream_t s) {
+    const h16 *x = (const h16 *)op->p[0], *g = (const h16 *)op->p[1], *b = (const h16 *)op->p[2];
+    h16 *out = (h16 *)op->p[3];
+    int rows = op->i[0], C = op->i[1], ldx = op->i[2], ldo = op->i[3];
+    if (!x || !g || !b || !out || rows <= 0 || C <= 0 || (C % 8) || C > 2048 || (ldx % 8) || (ldo % 8)) {
+        l2d_set_error("layernorm(tag %d): invalid arguments (rows=%d C=%d)", op->tag, rows, C);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, g, b, out, rows, C, ldx, ldo, op->f[0]);
+    return l2d_check_launch("layernorm", op->tag);
+}

@@ -1,0 +1,423 @@
+// Temporal attention kernels for gfx950 (HBM-bound, 1 flop/byte -> VALU + LDS, no MFMA).
+//
+// tattn_stream : the reference's StreamTemporalAttention core (stream_motion_module.py:99-213) in ONE pass
+//   over the KV-cache:  scatter the new K/V row into cache slot update_idx[n] (pre-PE, in place),
+//   K_l + k_pe[pe_idx[n,l]], q + q_pe[pe_idx[n,update_idx[n]]], 1xL scores + additive bias [N,L],
+//   softmax, P.(V_l + v_pe[..]).  The reference makes >= 5 cache-sized passes (K+pe / V+pe temporaries,
+//   head-reshape copies, .contiguous()); this kernel reads each cache byte exactly once.
+// tattn_warmup : VersatileAttention (motion_module.py:469-530): bidirectional FxF attention over the
+//   warm-up frames per pixel, writing the pre-PE K/V of the F frames into cache slots 0..F-1.
+//
+// Data layout / mapping.  Cache [N,2,T,L,C] fp16: for one (n, k|v, pixel) the L x C slab is contiguous.
+// A thread owns one 8-channel (16-byte) column `cc` of one pixel for all L slots, so
+//   * every wavefront load instruction covers whole contiguous 16 B x (C/8) rows -> fully coalesced,
+//   * the P.V accumulation is thread-local (no cross-lane traffic),
+//   * the only cross-thread step is the per-head score reduction over the d/8 threads of a head, done
+//     through LDS (padded rows, conflict-free float4 writes; same-address broadcast reads).
+// Block = PB pixels x TP threads (TP = C/8), PB chosen so that the block is 256..320 threads.
+// Masked slots (bias == -inf) are never read: their softmax weight is exactly 0.
+#include "common.h"
+
+struct TAttnArgs {
+    const h16 *qkv;
+    h16 *cache;
+    const h16 *q_pe, *k_pe, *v_pe;
+    const long long *pe_idx, *update_idx;
+    const h16 *bias;
+    h16 *out;
+    int N, T, C, L, H, variant;
+};
+
+__device__ __forceinline__ float dot8(h16x8 a, h16x8 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)b[e];
+    return s;
+}
+
+template <int TP, int PB, int L>
+__global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
+    constexpr int HG = TP / 8;  // threads per head (= d/8)
+    constexpr int LP = L + 4;   // padded LDS row (floats)
+    constexpr bool PRELOAD_V = (L <= 24);
+    extern __shared__ __attribute__((aligned(16))) float sp[];  // [PB*TP][LP]
+
+    const int tid = threadIdx.x;
+    const int p = tid / TP, cc = tid - p * TP;
+    const long long NT = (long long)a.N * a.T;
+    const long long pix = (long long)blockIdx.x * PB + p;
+    const bool valid = pix < NT;
+    const int n = valid ? (int)(pix / a.T) : 0;
+    const long long t = valid ? pix - (long long)n * a.T : 0;
+    const int C = a.C;
+    const int u = (int)a.update_idx[n];
+    const long long *pei = a.pe_idx + (long long)n * L;
+    const h16 *bi = a.bias + (long long)n * L;
+
+    h16x8 q8 = l2d_zero8(), k8 = l2d_zero8(), v8 = l2d_zero8();
+    h16 *kc = a.cache + (((long long)n * 2 + 0) * a.T + t) * L * C + cc * 8;
+    h16 *vc = a.cache + (((long long)n * 2 + 1) * a.T + t) * L * C + cc * 8;
+    if (valid) {
+        const h16 *src = a.qkv + pix * 3 * C + cc * 8;
+        q8 = l2d_ld8(src);
+        k8 = l2d_ld8(src + C);
+        v8 = l2d_ld8(src + 2 * C);
+        q8 = q8 + l2d_ld8(a.q_pe + pei[u] * C + cc * 8);   // fp16 add: same rounding point as the reference (:139)
+        l2d_st8(kc + (long long)u * C, k8);                 // cache stores pre-PE projections (:117-119)
+        l2d_st8(vc + (long long)u * C, v8);
+    }
+
+    float bl[L];
+    h16x8 vreg[PRELOAD_V ? L : 1];
+    float part[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        bl[l] = (float)bi[l];
+        const bool live = valid && bl[l] > -1e30f;
+        h16x8 kk = k8;
+        if (l != u) kk = live ? l2d_ld8(kc + (long long)l * C) : l2d_zero8();
+        if (PRELOAD_V) {
+            h16x8 vv = v8;
+            if (l != u) vv = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+            vreg[l] = vv;
+        }
+        h16x8 pe = l2d_ld8(a.k_pe + pei[l] * C + cc * 8);
+        kk = kk + pe;                                        // fp16 rounding of K+pe as in the reference (:140)
+        part[l] = dot8(q8, kk);
+    }
+    float *row = sp + (long long)tid * LP;
+#pragma unroll
+    for (int l = 0; l < L; l += 4) *reinterpret_cast<f32x4 *>(row + l) = (f32x4){part[l], part[l + 1], part[l + 2], part[l + 3]};
+    __syncthreads();
+    float s[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) s[l] = 0.f;
+    const int gs = p * TP + (cc / HG) * HG;
+    for (int j = 0; j < HG; ++j) {
+        const float *r = sp + (long long)(gs + j) * LP;
+#pragma unroll
+        for (int l = 0; l < L; l += 4) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>(r + l);
+            s[l] += x[0]; s[l + 1] += x[1]; s[l + 2] += x[2]; s[l + 3] += x[3];
+        }
+    }
+    const float scale = rsqrtf((float)(C / a.H));
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { s[l] = s[l] * scale + bl[l]; mx = fmaxf(mx, s[l]); }
+    float den = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { s[l] = __expf(s[l] - mx); den += s[l]; }
+    const float inv = 1.0f / den;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const bool live = valid && bl[l] > -1e30f;
+        h16x8 vv;
+        if (PRELOAD_V) {
+            vv = vreg[l];
+        } else {
+            vv = v8;
+            if (l != u) vv = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+        }
+        vv = vv + l2d_ld8(a.v_pe + pei[l] * C + cc * 8);     // (:141)
+        const float pl = s[l] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pl * (float)vv[e];
+    }
+    if (valid) {
+        h16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+        l2d_st8(a.out + pix * C + cc * 8, ov);
+    }
+}
+
+// Chunked variant: bounded register footprint for long windows (L = 24, 40) -- slots are processed CH at a
+// time (CH independent 16-byte loads in flight per thread), scores and probabilities live in the thread's
+// LDS row instead of L-sized register arrays.
+template <int TP, int PB, int L, int CH>
+__global__ __launch_bounds__(TP *PB) void tattn_stream_chunked_kernel(TAttnArgs a) {
+    constexpr int HG = TP / 8;
+    constexpr int LP = L + 4;
+    static_assert(L % CH == 0, "L must be a multiple of CH");
+    extern __shared__ __attribute__((aligned(16))) float sp[];
+
+    const int tid = threadIdx.x;
+    const int p = tid / TP, cc = tid - p * TP;
+    const long long NT = (long long)a.N * a.T;
+    const long long pix = (long long)blockIdx.x * PB + p;
+    const bool valid = pix < NT;
+    const int n = valid ? (int)(pix / a.T) : 0;
+    const long long t = valid ? pix - (long long)n * a.T : 0;
+    const int C = a.C;
+    const int u = (int)a.update_idx[n];
+    const long long *pei = a.pe_idx + (long long)n * L;
+    const h16 *bi = a.bias + (long long)n * L;
+
+    h16x8 q8 = l2d_zero8(), k8 = l2d_zero8(), v8 = l2d_zero8();
+    h16 *kc = a.cache + (((long long)n * 2 + 0) * a.T + t) * L * C + cc * 8;
+    h16 *vc = a.cache + (((long long)n * 2 + 1) * a.T + t) * L * C + cc * 8;
+    if (valid) {
+        const h16 *src = a.qkv + pix * 3 * C + cc * 8;
+        q8 = l2d_ld8(src);
+        k8 = l2d_ld8(src + C);
+        v8 = l2d_ld8(src + 2 * C);
+        q8 = q8 + l2d_ld8(a.q_pe + pei[u] * C + cc * 8);
+        l2d_st8(kc + (long long)u * C, k8);
+        l2d_st8(vc + (long long)u * C, v8);
+    }
+    float *row = sp + (long long)tid * LP;
+#pragma unroll 1
+    for (int l0 = 0; l0 < L; l0 += CH) {
+        h16x8 kk[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int l = l0 + i;
+            const bool live = valid && (float)bi[l] > -1e30f;
+            kk[i] = k8;
+            if (l != u) kk[i] = live ? l2d_ld8(kc + (long long)l * C) : l2d_zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int l = l0 + i;
+            h16x8 x = kk[i] + l2d_ld8(a.k_pe + pei[l] * C + cc * 8);
+            row[l] = dot8(q8, x);
+        }
+    }
+    __syncthreads();
+    float s[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) s[l] = 0.f;
+    const int gs = p * TP + (cc / HG) * HG;
+    for (int j = 0; j < HG; ++j) {
+        const float *r = sp + (long long)(gs + j) * LP;
+#pragma unroll
+        for (int l = 0; l < L; l += 4) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>(r + l);
+            s[l] += x[0]; s[l + 1] += x[1]; s[l + 2] += x[2]; s[l + 3] += x[3];
+        }
+    }
+    const float scale = rsqrtf((float)(C / a.H));
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { s[l] = s[l] * scale + (float)bi[l]; mx = fmaxf(mx, s[l]); }
+    float den = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { s[l] = __expf(s[l] - mx); den += s[l]; }
+    const float inv = 1.0f / den;
+    __syncthreads();   // every thread has finished reading the partial-score rows
+#pragma unroll
+    for (int l = 0; l < L; l += 4)
+        *reinterpret_cast<f32x4 *>(row + l) = (f32x4){s[l] * inv, s[l + 1] * inv, s[l + 2] * inv, s[l + 3] * inv};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll 1
+    for (int l0 = 0; l0 < L; l0 += CH) {
+        h16x8 vv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int l = l0 + i;
+            const bool live = valid && (float)bi[l] > -1e30f;
+            vv[i] = v8;
+            if (l != u) vv[i] = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int l = l0 + i;
+            h16x8 x = vv[i] + l2d_ld8(a.v_pe + pei[l] * C + cc * 8);
+            const float pl = row[l];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pl * (float)x[e];
+        }
+    }
+    if (valid) {
+        h16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+        l2d_st8(a.out + pix * C + cc * 8, ov);
+    }
+}
+
+template <int TP, int PB, int L>
+static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
+    long long NT = (long long)a.N * a.T;
+    int nb = (int)((NT + PB - 1) / PB);
+    size_t lds = (size_t)TP * PB * (L + 4) * sizeof(float);
+    // variant 0 (auto): register-resident for L <= 16, chunked (CH = 8) beyond; 1 / 2 / 3 force
+    // register-resident / chunked CH=8 / chunked CH=4 (used by the on-GPU A/B in bench.py --tune)
+    int v = a.variant;
+    if (v == 0) v = (L <= 16) ? 1 : 2;
+    if (v == 1 && L <= 16)
+        hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 3)
+        hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, 4>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else
+        hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, (L % 8 == 0 ? 8 : 4)>), dim3(nb), dim3(TP * PB), lds, s, a);
+    return L2D_OK;
+}
+
+template <int TP, int PB>
+static int launch_stream_l(const TAttnArgs &a, hipStream_t s) {
+    switch (a.L) {
+        case 12: return launch_stream_t<TP, PB, 12>(a, s);
+        case 16: return launch_stream_t<TP, PB, 16>(a, s);
+        case 24: return launch_stream_t<TP, PB, 24>(a, s);
+        case 40: return launch_stream_t<TP, PB, 40>(a, s);
+    }
+    l2d_set_error("tattn_stream: unsupported window L=%d (built: 12,16,24,40)", a.L);
+    return L2D_EINVAL;
+}
+
+static int tattn_common(const l2d_op *op, TAttnArgs &a, const char *what) {
+    a.qkv = (const h16 *)op->p[0]; a.cache = (h16 *)op->p[1];
+    a.q_pe = (const h16 *)op->p[2]; a.k_pe = (const h16 *)op->p[3]; a.v_pe = (const h16 *)op->p[4];
+    a.pe_idx = (const long long *)op->p[5]; a.update_idx = (const long long *)op->p[6];
+    a.bias = (const h16 *)op->p[7]; a.out = (h16 *)op->p[8];
+    a.N = op->i[0]; a.T = op->i[1]; a.C = op->i[2]; a.L = op->i[3]; a.H = op->i[4]; a.variant = op->i[5];
+    if (!a.qkv || !a.cache || !a.q_pe || !a.k_pe || !a.v_pe || !a.out || a.N <= 0 || a.T <= 0 || a.H != 8 ||
+        (a.C % 64) || a.L <= 0) {
+        l2d_set_error("%s(tag %d): invalid arguments (N=%d T=%d C=%d L=%d H=%d; need H=8, C%%64==0)", what, op->tag, a.N,
+                      a.T, a.C, a.L, a.H);
+        return L2D_EINVAL;
+    }
+    return L2D_OK;
+}
+
+int l2d_launch_tattn_stream(const l2d_op *op, hipStream_t s) {
+    TAttnArgs a;
+    int rc = tattn_common(op, a, "tattn_stream");
+    if (rc) return rc;
+    if (!a.pe_idx || !a.update_idx || !a.bias) {
+        l2d_set_error("tattn_stream(tag %d): pe_idx/update_idx/bias missing", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    switch (a.C) {
+        case 64: rc = launch_stream_l<8, 32>(a, s); break;
+        case 128: rc = launch_stream_l<16, 16>(a, s); break;
+        case 256: rc = launch_stream_l<32, 8>(a, s); break;
+        case 320: rc = launch_stream_l<40, 8>(a, s); break;
+        case 640: rc = launch_stream_l<80, 4>(a, s); break;
+        case 1280: rc = launch_stream_l<160, 2>(a, s); break;
+        default:
+            l2d_set_error("tattn_stream(tag %d): unsupported C=%d (built: 64,128,256,320,640,1280)", op->tag, a.C);
+            return L2D_EINVAL;
+    }
+    if (rc) return rc;
+    return l2d_check_launch("tattn_stream", op->tag);
+}
+
+// ------------------------------------------------------------------------------------------- warm-up
+template <int TP, int PB, int F>
+__global__ __launch_bounds__(TP *PB) void tattn_warmup_kernel(TAttnArgs a) {
+    constexpr int HG = TP / 8;
+    constexpr int LP = F * F + 4;
+    extern __shared__ __attribute__((aligned(16))) float sp[];
+    const int tid = threadIdx.x;
+    const int p = tid / TP, cc = tid - p * TP;
+    const long long t = (long long)blockIdx.x * PB + p;
+    const bool valid = t < a.T;
+    const int C = a.C, L = a.L;
+    h16x8 q[F], k[F], v[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        q[f] = k[f] = v[f] = l2d_zero8();
+        if (valid) {
+            const h16 *src = a.qkv + ((long long)f * a.T + t) * 3 * C + cc * 8;
+            q[f] = l2d_ld8(src);
+            k[f] = l2d_ld8(src + C);
+            v[f] = l2d_ld8(src + 2 * C);
+            // cache_row [2,T,L,C]: slots 0..F-1 take the pre-PE projections (motion_module.py:492-493)
+            l2d_st8(a.cache + ((0LL * a.T + t) * L + f) * C + cc * 8, k[f]);
+            l2d_st8(a.cache + ((1LL * a.T + t) * L + f) * C + cc * 8, v[f]);
+        }
+        q[f] = q[f] + l2d_ld8(a.q_pe + (long long)f * C + cc * 8);
+        k[f] = k[f] + l2d_ld8(a.k_pe + (long long)f * C + cc * 8);
+        v[f] = v[f] + l2d_ld8(a.v_pe + (long long)f * C + cc * 8);
+    }
+    float *row = sp + (long long)tid * LP;
+#pragma unroll
+    for (int fq = 0; fq < F; ++fq)
+#pragma unroll
+        for (int fk = 0; fk < F; fk += 4)
+            *reinterpret_cast<f32x4 *>(row + fq * F + fk) =
+                (f32x4){dot8(q[fq], k[fk]), dot8(q[fq], k[fk + 1]), dot8(q[fq], k[fk + 2]), dot8(q[fq], k[fk + 3])};
+    __syncthreads();
+    const int gs = p * TP + (cc / HG) * HG;
+    const float scale = rsqrtf((float)(C / a.H));
+#pragma unroll
+    for (int fq = 0; fq < F; ++fq) {
+        float s[F];
+#pragma unroll
+        for (int fk = 0; fk < F; ++fk) s[fk] = 0.f;
+        for (int j = 0; j < HG; ++j) {
+            const float *r = sp + (long long)(gs + j) * LP + fq * F;
+#pragma unroll
+            for (int fk = 0; fk < F; fk += 4) {
+                f32x4 x = *reinterpret_cast<const f32x4 *>(r + fk);
+                s[fk] += x[0]; s[fk + 1] += x[1]; s[fk + 2] += x[2]; s[fk + 3] += x[3];
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int fk = 0; fk < F; ++fk) { s[fk] *= scale; mx = fmaxf(mx, s[fk]); }
+        float den = 0.f;
+#pragma unroll
+        for (int fk = 0; fk < F; ++fk) { s[fk] = __expf(s[fk] - mx); den += s[fk]; }
+        const float inv = 1.0f / den;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int fk = 0; fk < F; ++fk) {
+            const float pl = s[fk] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pl * (float)v[fk][e];
+        }
+        if (valid) {
+            h16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+            l2d_st8(a.out + ((long long)fq * a.T + t) * C + cc * 8, ov);
+        }
+    }
+}
+
+template <int TP, int PB>
+static int launch_warm_t(const TAttnArgs &a, hipStream_t s) {
+    constexpr int F = 8;
+    int nb = (a.T + PB - 1) / PB;
+    size_t lds = (size_t)TP * PB * (F * F + 4) * sizeof(float);
+    hipLaunchKernelGGL((tattn_warmup_kernel<TP, PB, F>), dim3(nb), dim3(TP * PB), lds, s, a);
+    return L2D_OK;
+}
+
+int l2d_launch_tattn_warmup(const l2d_op *op, hipStream_t s) {
+    TAttnArgs a;
+    int rc = tattn_common(op, a, "tattn_warmup");
+    if (rc) return rc;
+    int F = a.N;  // i0 carries the number of warm-up frames
+    if (F != 8 || F > a.L) {
+        l2d_set_error("tattn_warmup(tag %d): F=%d unsupported (built: F=8 <= L)", op->tag, F);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    // a block stages F*F partial scores per thread in LDS (272 B/thread): blocks of <= 160 threads
+    switch (a.C) {
+        case 64: rc = launch_warm_t<8, 16>(a, s); break;
+        case 128: rc = launch_warm_t<16, 8>(a, s); break;
+        case 256: rc = launch_warm_t<32, 4>(a, s); break;
+        case 320: rc = launch_warm_t<40, 4>(a, s); break;
+        case 640: rc = launch_warm_t<80, 2>(a, s); break;
+        case 1280: rc = launch_warm_t<160, 1>(a, s); break;
+        default:
+            l2d_set_error("tattn_warmup(tag %d): unsupported C=%d", op->tag, a.C);
+            return L2D_EINVAL;
+    }
+    if (rc) return rc;
+    return l2d_check_launch("tattn_warmup", op->tag);
+}

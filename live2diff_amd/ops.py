@@ -1,0 +1,221 @@
+"""Builders for `l2d_op` records (include/l2d.h) from torch device tensors, plus the one-time weight
+packers.  Everything here is plumbing: pointers, sizes and strides; the arithmetic is in csrc/*.hip.
+
+Each builder returns `(op, keepalive_tensors)` so that a plan (`_lib.OpList`) can keep the buffers alive.
+"""
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import L2dOp
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+DRY_RUN = False   # set by the CPU test-suite together with l2d_set_dry_run(1): plans are built and validated, never launched
+
+
+def _h(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float16 and (t.is_cuda or DRY_RUN), (t.dtype, t.device)
+    return t
+
+
+# ----------------------------------------------------------------------------- weight packing (one-time)
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [Cout, 9*CinP] fp16 with k = tap*CinP + ci, CinP = round_up(Cin, 64) (zero padded)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    cinp = round_up(cin, 64)
+    out = torch.zeros(cout, 9, cinp, dtype=torch.float16, device=w.device)
+    out[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, 9, cin).to(torch.float16)
+    return out.reshape(cout, 9 * cinp).contiguous()
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    """[Nout,K] (or [Nout,K,1,1]) -> [Nout, round_up(K,64)] fp16, zero padded."""
+    w = w.reshape(w.shape[0], -1)
+    n, k = w.shape
+    kp = round_up(k, 64)
+    out = torch.zeros(n, kp, dtype=torch.float16, device=w.device)
+    out[:, :k] = w.to(torch.float16)
+    return out.contiguous()
+
+
+def geglu_perm(c4: int, device) -> torch.Tensor:
+    """Row permutation for the GEGLU projection [8C, C]: packed rows are 16 value rows then the 16 matching
+    gate rows, so that value and gate of one output column meet in the same MFMA lane (igemm.hip epilogue)."""
+    assert c4 % 16 == 0
+    blk = torch.arange(c4 // 16, device=device)[:, None] * 16 + torch.arange(16, device=device)[None]
+    return torch.stack([blk, blk + c4], dim=1).reshape(-1)
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    perm = geglu_perm(w.shape[0] // 2, w.device)
+    return pack_linear(w[perm]), b[perm].float().contiguous()
+
+
+def f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.float().contiguous()
+
+
+# ----------------------------------------------------------------------------- op builders
+def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
+          rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
+          batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0):
+    """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors."""
+    op = L2dOp()
+    op.kind = _lib.OP_IGEMM
+    es = 2
+    op.p[0] = _ptr(_h(x1)) + x1_off * es
+    op.p[1] = _ptr(x2) if x2 is not None else None
+    op.p[2] = _ptr(_h(w)) + w_off * es
+    op.p[3] = _ptr(bias)
+    op.p[4] = _ptr(rowbias)
+    op.p[5] = (_ptr(res) + res_off * es) if res is not None else None
+    op.p[6] = _ptr(_h(out)) + out_off * es
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32
+    vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
+            rows_per_bias, epi, batch]
+    for j, v in enumerate(vals):
+        op.i[j] = int(v)
+    op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
+    return op, (x1, x2, w, bias, rowbias, res, out)
+
+
+def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):
+    op = L2dOp()
+    op.kind = _lib.OP_GN_STATS
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), _ptr(x2), _ptr(partial)
+    for j, v in enumerate([B, T, C1, C2, ld1, ld2, G, nchunk, 0]):
+        op.i[j] = int(v)
+    return op, (x1, x2, partial)
+
+
+def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0):
+    op = L2dOp()
+    op.kind = _lib.OP_GN_APPLY
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), _ptr(x2), _ptr(partial)
+    op.p[3], op.p[4], op.p[5] = _ptr(_h(gamma)), _ptr(_h(beta)), _ptr(_h(out))
+    for j, v in enumerate([B, T, C1, C2, ld1, ld2, G, nchunk, 1 if silu else 0]):
+        op.i[j] = int(v)
+    op.f[0] = float(eps)
+    return op, (x1, x2, partial, gamma, beta, out)
+
+
+def layernorm(x, gamma, beta, out, *, rows, C, ldx, ldo, eps=1e-5):
+    op = L2dOp()
+    op.kind = _lib.OP_LAYERNORM
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(x)), _ptr(_h(gamma)), _ptr(_h(beta)), _ptr(_h(out))
+    for j, v in enumerate([rows, C, ldx, ldo]):
+        op.i[j] = int(v)
+    op.f[0] = float(eps)
+    return op, (x, gamma, beta, out)
+
+
+def flash_attn(q, k, vt, out, *, B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, q_off=0, k_off=0, vt_off=0):
+    op = L2dOp()
+    op.kind = _lib.OP_FLASH_ATTN
+    op.p[0] = _ptr(_h(q)) + q_off * 2
+    op.p[1] = _ptr(_h(k)) + k_off * 2
+    op.p[2] = _ptr(_h(vt)) + vt_off * 2
+    op.p[3] = _ptr(_h(out))
+    for j, v in enumerate([B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo]):
+        op.i[j] = int(v)
+    op.l[0], op.l[1], op.l[2], op.l[3] = int(sq), int(sk), int(svt), int(so)
+    return op, (q, k, vt, out)
+
+
+def tattn_stream(qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out, *, N, T, C, L, H, variant=0):
+    assert cache.dtype == torch.float16 and cache.is_contiguous() and tuple(cache.shape) == (N, 2, T, L, C), \
+        (cache.dtype, tuple(cache.shape), (N, 2, T, L, C))
+    assert pe_idx.dtype == torch.int64 and update_idx.dtype == torch.int64 and bias.dtype == torch.float16
+    op = L2dOp()
+    op.kind = _lib.OP_TATTN_STREAM
+    for j, t in enumerate([qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out]):
+        op.p[j] = _ptr(t)
+    for j, v in enumerate([N, T, C, L, H, variant]):
+        op.i[j] = int(v)
+    return op, (qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out)
+
+
+def tattn_warmup(qkv, cache_row, q_pe, k_pe, v_pe, out, *, F, T, C, L, H):
+    assert cache_row.dtype == torch.float16 and cache_row.is_contiguous() and tuple(cache_row.shape) == (2, T, L, C)
+    op = L2dOp()
+    op.kind = _lib.OP_TATTN_WARMUP
+    for j, t in enumerate([qkv, cache_row, q_pe, k_pe, v_pe]):
+        op.p[j] = _ptr(t)
+    op.p[8] = _ptr(out)
+    for j, v in enumerate([F, T, C, L, H]):
+        op.i[j] = int(v)
+    return op, (qkv, cache_row, q_pe, k_pe, v_pe, out)
+
+
+def skinny_linear(a, w, bias, out, *, M, K, Nout, silu_out=False, ldo=None):
+    op = L2dOp()
+    op.kind = _lib.OP_SKINNY_LINEAR
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(a)), _ptr(_h(w)), _ptr(bias), _ptr(out)
+    is_f = out.dtype == torch.float32
+    for j, v in enumerate([M, K, Nout, 1 if silu_out else 0, 1 if is_f else 0, ldo if ldo is not None else Nout]):
+        op.i[j] = int(v)
+    return op, (a, w, bias, out)
+
+
+def timestep_embed(t, out, *, N, dim):
+    assert t.dtype == torch.int64
+    op = L2dOp()
+    op.kind = _lib.OP_TIMESTEP_EMBED
+    op.p[0], op.p[1] = _ptr(t), _ptr(_h(out))
+    op.i[0], op.i[1] = N, dim
+    return op, (t, out)
+
+
+def nchw_to_nhwc(x, out, *, B, C, HW, Cpad):
+    op = L2dOp()
+    op.kind = _lib.OP_NCHW_TO_NHWC
+    op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
+    for j, v in enumerate([B, C, HW, Cpad]):
+        op.i[j] = int(v)
+    return op, (x, out)
+
+
+def nhwc_to_nchw(x, out, *, B, C, HW, ld):
+    op = L2dOp()
+    op.kind = _lib.OP_NHWC_TO_NCHW
+    op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
+    for j, v in enumerate([B, C, HW, ld]):
+        op.i[j] = int(v)
+    return op, (x, out)
+
+
+def lcm_step(x, eps, scal, x0, *, N, per):
+    op = L2dOp()
+    op.kind = _lib.OP_LCM_STEP
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(x)), _ptr(_h(eps)), _ptr(scal), _ptr(_h(x0))
+    op.i[0], op.i[1] = N, per
+    return op, (x, eps, scal, x0)
+
+
+def copy(src, dst, nbytes):
+    op = L2dOp()
+    op.kind = _lib.OP_COPY
+    op.p[0], op.p[1] = _ptr(src), _ptr(dst)
+    op.l[0] = int(nbytes)
+    return op, (src, dst)
+
+
+def run(op_and_keep, stream=None):
+    """Run a single op immediately (unit tests)."""
+    op, keep = op_and_keep
+    pl = _lib.OpList()
+    pl.append(op, *keep)
+    pl.run(stream)

@@ -1,0 +1,624 @@
+"""HipStreamingUNet -- the object that occupies the reference's `stream.unet` slot.
+
+Boundary (reference): `StreamAnimateDiffusionDepth.unet`, called at
+live2diff/pipeline_stream_animation_depth.py:456-466 with the signature of
+`UNet3DConditionStreamingModel.forward` (unet_depth_streaming.py:429-448) /
+`UNet2DConditionModelDepthEngine.__call__` (acceleration/tensorrt/engine.py:142-153); the warm-up twin
+(`unet_warmup`, unet_depth_warmup.py:407-590, called at pipeline :320-328) is `HipStreamingUNet.warmup`.
+
+Design (MI355X-first, not a module-by-module translation):
+  * one channels-last fp16 activation layout `[B*T, C]` end to end; the only layout conversions of a step
+    are on the 4-channel latents at the boundary;
+  * weights are ingested once from a reference-keyed `state_dict` and re-packed for the kernels
+    (3x3 taps-major, q|k fused, q|k|v fused for the temporal layers, GEGLU value/gate interleaved, all
+    time_emb_proj / all text K,V projections concatenated into single GEMMs);
+  * a UNet step is a static *plan* -- an array of `l2d_op` records, built once per (H, W, N, L) -- that the
+    native executor replays (`l2d_run_ops`, or a captured hipGraph): ~650 kernels, no Python in the loop;
+  * the KV-cache stays in the reference interchange layout `[N,2,T,L,C]` and is updated IN PLACE, so the
+    caller's `kv_cache_list` semantics (pipeline :468-469) hold and nothing cache-sized is ever copied.
+No torch compute ops are used on the path (torch provides HBM allocations, the stream, and the tiny
+host-to-static-buffer input copies).
+"""
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+from .config import UNetConfig, motion_module_layout
+from .ops import round_up
+
+TEXT_PAD = 80   # 77 CLIP tokens padded to a multiple of 4 (igemm stores 4 channels per lane)
+
+
+class UNetOutput(dict):
+    """`out["sample"]`, `out["kv_cache"]`, `out.sample`, `out.kv_cache`, `out[0]`
+    (reference UNet3DConditionStreamingOutput, unet_depth_streaming.py:29-32)."""
+
+    def __init__(self, sample, kv_cache):
+        super().__init__(sample=sample, kv_cache=kv_cache)
+        self.sample, self.kv_cache = sample, kv_cache
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return (self.sample, self.kv_cache)[k]
+        return dict.__getitem__(self, k)
+
+
+def sinusoid_pe(max_len: int, dim: int, device) -> torch.Tensor:
+    """reference positional_encoding.py:12-16"""
+    import math
+
+    pos = torch.arange(max_len, dtype=torch.float32, device=device).unsqueeze(1)
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32, device=device) * (-math.log(10000.0) / dim))
+    pe = torch.zeros(max_len, dim, device=device)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class _Arena:
+    """Size-keyed free list of device buffers: intermediates of a static plan reuse HBM (and stay hot in the
+    256 MB Infinity Cache) instead of every op getting a private allocation."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[tuple, List[torch.Tensor]] = {}
+        self.all: List[torch.Tensor] = []
+
+    def alloc(self, numel: int, dtype=torch.float16) -> torch.Tensor:
+        key = (int(numel), dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        t = torch.empty(int(numel), dtype=dtype, device=self.device)
+        self.all.append(t)
+        return t
+
+    def release(self, t: Optional[torch.Tensor]):
+        if t is not None:
+            self.free.setdefault((t.numel(), t.dtype), []).append(t)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.all)
+
+
+class _Act:
+    """channels-last activation: buf holds [B*H*W, C] halfs (ld == C)."""
+    __slots__ = ("buf", "C", "H", "W")
+
+    def __init__(self, buf, C, H, W):
+        self.buf, self.C, self.H, self.W = buf, C, H, W
+
+
+class HipStreamingUNet:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig, height: int, width: int,
+                 denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
+                 tattn_variant: int = 0):
+        """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names."""
+        assert cfg.num_heads == 8 and cfg.temporal_heads == 8
+        assert height % 8 == 0 and width % 8 == 0, "latent size must be divisible by 8 (3 down-samplings, T%4==0)"
+        self.cfg, self.h, self.w, self.N = cfg, height, width, denoising_steps_num
+        self.device = torch.device(device)
+        self.F = cfg.sink_size if warmup_frames is None else warmup_frames
+        self.use_graph = use_graph
+        self.tattn_variant = tattn_variant
+        self.dtype = torch.float16
+        self.config = SimpleNamespace(in_channels=cfg.in_channels)      # read by the reference wrapper (:524)
+        self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()   # raises unless a gfx950 is present
+        self.mm_layout = motion_module_layout(cfg, height, width)
+        self._pack_weights(state_dict)
+        self._plans = {}
+        self._graph = {}
+
+    # ------------------------------------------------------------------ reference-compatible surface
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def forward(self, *a, **k):
+        return self(*a, **k)
+
+    def set_info_for_attn(self, height: int, width: int, *a, **k):
+        assert (height, width) == (self.h, self.w), "static shapes per instance (TensorRT precedent: models.py:289-291)"
+
+    def prepare_cache(self, denoising_steps_num: int) -> List[torch.Tensor]:
+        """Zero KV caches [N,2,h*w,L,C] fp16 in motion_module_idx order
+        (reference unet_depth_streaming.py:283-302 + stream_motion_module.py:57-77)."""
+        return [torch.zeros(denoising_steps_num, 2, hh * ww, self.cfg.window_size, c, dtype=torch.float16,
+                            device=self.device) for (c, hh, ww, _l) in self.mm_layout]
+
+    # ------------------------------------------------------------------ weights
+    def _pack_weights(self, sd):
+        cfg, dev = self.cfg, self.device
+        g = lambda k: sd[k].to(device=dev)
+        W = {}
+        self.W = W
+
+        def conv3(name):
+            W[name + ".w"] = ops.pack_conv3x3(g(name + ".weight"))
+            W[name + ".b"] = ops.f32(g(name + ".bias"))
+
+        def lin(name, bias=True):
+            W[name + ".w"] = ops.pack_linear(g(name + ".weight"))
+            if bias:
+                W[name + ".b"] = ops.f32(g(name + ".bias"))
+
+        def norm(name):
+            W[name + ".g"] = g(name + ".weight").to(torch.float16).contiguous()
+            W[name + ".beta"] = g(name + ".bias").to(torch.float16).contiguous()
+
+        def ff(name):
+            w, b = ops.pack_geglu(g(name + ".net.0.proj.weight"), g(name + ".net.0.proj.bias"))
+            W[name + ".w1"], W[name + ".b1"] = w, b
+            lin(name + ".net.2")
+
+        self.temb_names, self.temb_offsets = [], {}
+        temb_w, temb_b = [], []
+        self.text_offsets = {}
+        text_k, text_v = [], []
+
+        def resnet(name):
+            norm(name + ".norm1"); conv3(name + ".conv1"); norm(name + ".norm2"); conv3(name + ".conv2")
+            if (name + ".conv_shortcut.weight") in sd:
+                lin(name + ".conv_shortcut")
+            self.temb_offsets[name] = sum(t.shape[0] for t in temb_w)
+            temb_w.append(g(name + ".time_emb_proj.weight").to(torch.float16))
+            temb_b.append(g(name + ".time_emb_proj.bias").float())
+
+        def spatial(name):
+            norm(name + ".norm"); lin(name + ".proj_in"); lin(name + ".proj_out")
+            b = name + ".transformer_blocks.0"
+            for n in ("norm1", "norm2", "norm3"):
+                norm(b + "." + n)
+            W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([g(b + ".attn1.to_q.weight"), g(b + ".attn1.to_k.weight")], 0))
+            W[b + ".attn1.v"] = ops.pack_linear(g(b + ".attn1.to_v.weight"))
+            lin(b + ".attn1.to_out.0")
+            lin(b + ".attn2.to_q", bias=False)
+            self.text_offsets[name] = sum(t.shape[0] for t in text_k)
+            text_k.append(g(b + ".attn2.to_k.weight").to(torch.float16))
+            text_v.append(g(b + ".attn2.to_v.weight").to(torch.float16))
+            lin(b + ".attn2.to_out.0")
+            ff(b + ".ff")
+
+        self.pe_tables = {}
+
+        def motion(name, C):
+            t = name + ".temporal_transformer"
+            norm(t + ".norm"); lin(t + ".proj_in"); lin(t + ".proj_out")
+            b = t + ".transformer_blocks.0"
+            L = cfg.window_size
+            if C not in self.pe_tables:
+                self.pe_tables[C] = sinusoid_pe(max(cfg.temporal_max_len, L), C, dev)
+            pe = self.pe_tables[C][:L]
+            for j in range(2):
+                a = b + f".attention_blocks.{j}"
+                wq, wk, wv = g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")
+                W[a + ".qkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0))
+                # pre-projected positional encodings (reference prepare_pe_buffer, stream_motion_module.py:79-97)
+                for nm, w_ in (("q_pe", wq), ("k_pe", wk), ("v_pe", wv)):
+                    W[a + "." + nm] = (pe @ w_.float().t()).to(torch.float16).contiguous()
+                lin(a + ".to_out.0")
+                norm(b + f".norms.{j}")
+            norm(b + ".ff_norm")
+            ff(b + ".ff")
+
+        conv3("conv_in")
+        conv3("flow_conv_in.conv_in")
+        i = 0
+        while f"flow_conv_in.blocks.{i}.weight" in sd:
+            conv3(f"flow_conv_in.blocks.{i}")
+            i += 1
+        self.n_map_blocks = i
+        conv3("flow_conv_in.conv_out")
+        W["time_embedding.linear_1.w"] = g("time_embedding.linear_1.weight").to(torch.float16).contiguous()
+        W["time_embedding.linear_1.b"] = ops.f32(g("time_embedding.linear_1.bias"))
+        W["time_embedding.linear_2.w"] = g("time_embedding.linear_2.weight").to(torch.float16).contiguous()
+        W["time_embedding.linear_2.b"] = ops.f32(g("time_embedding.linear_2.bias"))
+        nl, ch = cfg.num_levels, cfg.block_out_channels
+        for i in range(nl):
+            for j in range(cfg.layers_per_block):
+                resnet(f"down_blocks.{i}.resnets.{j}")
+                if i != nl - 1:
+                    spatial(f"down_blocks.{i}.attentions.{j}")
+                motion(f"down_blocks.{i}.motion_modules.{j}", ch[i])
+            if i != nl - 1:
+                conv3(f"down_blocks.{i}.downsamplers.0.conv")
+        resnet("mid_block.resnets.0"); spatial("mid_block.attentions.0"); resnet("mid_block.resnets.1")
+        rev = list(reversed(ch))
+        for i in range(nl):
+            for j in range(cfg.layers_per_block + 1):
+                resnet(f"up_blocks.{i}.resnets.{j}")
+                if i != 0:
+                    spatial(f"up_blocks.{i}.attentions.{j}")
+                motion(f"up_blocks.{i}.motion_modules.{j}", rev[i])
+            if i != nl - 1:
+                conv3(f"up_blocks.{i}.upsamplers.0.conv")
+        norm("conv_norm_out"); conv3("conv_out")
+        W["temb_all.w"] = torch.cat(temb_w, 0).contiguous()          # [sum Cout, 4*c0]
+        W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
+        self.temb_total = W["temb_all.w"].shape[0]
+        W["text_k.w"] = ops.pack_linear(torch.cat(text_k, 0))         # [sum C, Kp(text)]
+        W["text_v.w"] = ops.pack_linear(torch.cat(text_v, 0))
+        self.text_total = W["text_k.w"].shape[0]
+        self.text_kp = W["text_k.w"].shape[1]
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.W.values())
+
+    # ------------------------------------------------------------------ plan construction
+    def _build_plan(self, mode: str, kv_cache: List[torch.Tensor]):
+        cfg, dev, W = self.cfg, self.device, self.W
+        B = self.N if mode == "stream" else self.F          # frames processed as the batch axis
+        Bt = self.N if mode == "stream" else 1              # rows of timestep / text inputs
+        h, w = self.h, self.w
+        L, G = cfg.window_size, cfg.norm_num_groups
+        ar = _Arena(dev)
+        pl = _lib.OpList()
+        st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, arena=ar, tattn_ops=[])
+
+        def add(opk):
+            op, keep = opk
+            pl.append(op, *keep)
+            return op
+
+        # ---- static inputs
+        st.in_sample = torch.zeros(B, cfg.in_channels, h * w, dtype=torch.float16, device=dev)
+        st.in_depth = torch.zeros_like(st.in_sample)
+        st.in_t = torch.zeros(Bt, dtype=torch.int64, device=dev)
+        st.in_enc = torch.zeros(Bt, TEXT_PAD, self.text_kp, dtype=torch.float16, device=dev)
+        if mode == "stream":
+            st.in_bias = torch.zeros(B, L, dtype=torch.float16, device=dev)
+            st.in_pe_idx = torch.zeros(B, L, dtype=torch.int64, device=dev)
+            st.in_upd = torch.zeros(B, dtype=torch.int64, device=dev)
+        st.out_sample = torch.zeros(B, cfg.out_channels, h * w, dtype=torch.float16, device=dev)
+
+        # ---- helpers
+        def new_act(C, H_, W_):
+            return _Act(ar.alloc(B * H_ * W_ * C), C, H_, W_)
+
+        def free(a: Optional[_Act]):
+            if a is not None:
+                ar.release(a.buf)
+
+        def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
+            T = x.H * x.W
+            C2 = x2.C if x2 is not None else 0
+            nchunk = max(1, min(32, T // 64))
+            partial = ar.alloc(B * nchunk * G * 2, torch.float32)
+            out = new_act(x.C + C2, x.H, x.W)
+            kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
+                      ld2=C2)
+            add(ops.gn_stats(x.buf, partial, **kw))
+            add(ops.gn_apply(x.buf, partial, W[name + ".g"], W[name + ".beta"], out.buf, eps=eps, silu=silu, **kw))
+            ar.release(partial)
+            return out
+
+        def conv3(x: _Act, name, stride=1, ups=0, epi=0, res: Optional[_Act] = None, rowbias=None) -> _Act:
+            wt = W[name + ".w"]
+            cout = wt.shape[0]
+            cinp = wt.shape[1] // 9
+            Hin, Win = x.H, x.W
+            if ups:
+                Ho, Wo = Hin * 2, Win * 2
+            elif stride == 2:
+                Ho, Wo = (Hin - 1) // 2 + 1, (Win - 1) // 2 + 1
+            else:
+                Ho, Wo = Hin, Win
+            out = new_act(cout, Ho, Wo)
+            kw = {}
+            if rowbias is not None:
+                off = rowbias
+                kw = dict(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(Ho * Wo if mode == "stream" else B * Ho * Wo))
+            opk = ops.igemm(x.buf, wt, out.buf, M=B * Ho * Wo, Nout=cout, C1=x.C, ldx1=x.C, CinP=cinp, ldo=cout,
+                            bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
+                            taps=9, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, stride=stride, ups=ups, epi=epi, **kw)
+            if rowbias is not None:
+                opk[0].p[4] = st.temb_all.data_ptr() + 4 * rowbias
+            add(opk)
+            return out
+
+        def linear_raw(xbuf, M, K, ldx, wt, outbuf, ldo, bias=None, res=None, ldr=0, epi=0, x2=None, C2=0, ldx2=0,
+                       **kw):
+            nout = wt.shape[0]
+            add(ops.igemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
+                          res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw))
+
+        def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None) -> _Act:
+            wt = W[wkey or (name + ".w")]
+            out = new_act(wt.shape[0], x.H, x.W)
+            linear_raw(x.buf, B * x.H * x.W, x.C, x.C, wt, out.buf, wt.shape[0], bias=(W[name + ".b"] if bias else None),
+                       res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
+                       x2=(x2.buf if x2 is not None else None), C2=(x2.C if x2 is not None else 0),
+                       ldx2=(x2.C if x2 is not None else 0))
+            return out
+
+        def layernorm(x: _Act, name) -> _Act:
+            out = new_act(x.C, x.H, x.W)
+            add(ops.layernorm(x.buf, W[name + ".g"], W[name + ".beta"], out.buf, rows=B * x.H * x.W, C=x.C, ldx=x.C, ldo=x.C))
+            return out
+
+        def geglu_ff(x: _Act, name, res: _Act) -> _Act:
+            w1 = W[name + ".w1"]
+            c4 = w1.shape[0] // 2
+            hid = new_act(c4, x.H, x.W)
+            linear_raw(x.buf, B * x.H * x.W, x.C, x.C, w1, hid.buf, c4, bias=W[name + ".b1"], epi=1)
+            out = linear(hid, name + ".net.2", res=res)
+            free(hid)
+            return out
+
+        def resnet(x: _Act, name, skip: Optional[_Act] = None) -> _Act:
+            hn = gn(x, name + ".norm1", cfg.norm_eps, True, x2=skip)
+            h1 = conv3(hn, name + ".conv1", rowbias=self.temb_offsets[name])
+            free(hn)
+            h2 = gn(h1, name + ".norm2", cfg.norm_eps, True)
+            free(h1)
+            if (name + ".conv_shortcut.w") in W:
+                sc = linear(x, name + ".conv_shortcut", x2=skip)
+                out = conv3(h2, name + ".conv2", res=sc)
+                free(sc)
+            else:
+                assert skip is None
+                out = conv3(h2, name + ".conv2", res=x)
+            free(h2)
+            return out
+
+        def spatial(x: _Act, name) -> _Act:
+            T, C = x.H * x.W, x.C
+            d = C // cfg.num_heads
+            hn = gn(x, name + ".norm", cfg.transformer_norm_eps, False)
+            y = linear(hn, name + ".proj_in")
+            free(hn)
+            b = name + ".transformer_blocks.0"
+            # --- self attention
+            n1 = layernorm(y, b + ".norm1")
+            qk = ar.alloc(B * T * 2 * C)
+            linear_raw(n1.buf, B * T, C, C, W[b + ".attn1.qk"], qk, 2 * C)
+            ldvt = round_up(T, 8)
+            vt = ar.alloc(B * C * ldvt)
+            # V^T[b] = Wv . n1[b]^T : the same GEMM with operand roles swapped (tokens act as "channels")
+            wv = W[b + ".attn1.v"]
+            add(ops.igemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
+                          sw=T * C, so=C * ldvt))
+            free(n1)
+            ao = new_act(C, x.H, x.W)
+            add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
+                               ldo=C, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, k_off=C))
+            ar.release(qk); ar.release(vt)
+            y2 = linear(ao, b + ".attn1.to_out.0", res=y)
+            free(ao); free(y)
+            # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start)
+            n2 = layernorm(y2, b + ".norm2")
+            q2 = linear(n2, b + ".attn2.to_q", bias=False)
+            free(n2)
+            off = self.text_offsets[name]
+            ao = new_act(C, x.H, x.W)
+            add(ops.flash_attn(q2.buf, st.text_k, st.text_vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=st.text_len,
+                               ldq=C, ldk=self.text_total, ldvt=TEXT_PAD, ldo=C, sq=T * C,
+                               sk=(TEXT_PAD * self.text_total if Bt > 1 else 0),
+                               svt=(self.text_total * TEXT_PAD if Bt > 1 else 0), so=T * C, k_off=off, vt_off=off * TEXT_PAD))
+            free(q2)
+            y3 = linear(ao, b + ".attn2.to_out.0", res=y2)
+            free(ao); free(y2)
+            n3 = layernorm(y3, b + ".norm3")
+            y4 = geglu_ff(n3, b + ".ff", res=y3)
+            free(n3); free(y3)
+            out = linear(y4, name + ".proj_out", res=x)
+            free(y4)
+            return out
+
+        def motion(x: _Act, name, idx_base: int) -> _Act:
+            T, C = x.H * x.W, x.C
+            t = name + ".temporal_transformer"
+            hn = gn(x, t + ".norm", cfg.transformer_norm_eps, False)
+            y = linear(hn, t + ".proj_in")
+            free(hn)
+            b = t + ".transformer_blocks.0"
+            for j in range(2):
+                a = b + f".attention_blocks.{j}"
+                nrm = layernorm(y, b + f".norms.{j}")
+                qkv = ar.alloc(B * T * 3 * C)
+                linear_raw(nrm.buf, B * T, C, C, W[a + ".qkv"], qkv, 3 * C)
+                free(nrm)
+                ao = new_act(C, x.H, x.W)
+                idx = idx_base + j
+                cache = kv_cache[idx]
+                if mode == "stream":
+                    op = add(ops.tattn_stream(qkv, cache, W[a + ".q_pe"], W[a + ".k_pe"], W[a + ".v_pe"], st.in_pe_idx,
+                                              st.in_upd, st.in_bias, ao.buf, N=B, T=T, C=C, L=L, H=cfg.temporal_heads,
+                                              variant=self.tattn_variant))
+                else:
+                    op = add(ops.tattn_warmup(qkv, cache[0], W[a + ".q_pe"], W[a + ".k_pe"], W[a + ".v_pe"], ao.buf,
+                                              F=B, T=T, C=C, L=L, H=cfg.temporal_heads))
+                st.tattn_ops.append((op.tag, idx))
+                ar.release(qkv)
+                y2 = linear(ao, a + ".to_out.0", res=y)
+                free(ao); free(y)
+                y = y2
+            nrm = layernorm(y, b + ".ff_norm")
+            y2 = geglu_ff(nrm, b + ".ff", res=y)
+            free(nrm); free(y)
+            out = linear(y2, t + ".proj_out", res=x)
+            free(y2)
+            return out
+
+        # ---- time embedding: sinusoid -> MLP -> SiLU -> every resnet's time_emb_proj in ONE skinny GEMM
+        c0, E = cfg.block_out_channels[0], cfg.time_embed_dim
+        t_sin = torch.zeros(Bt, c0, dtype=torch.float16, device=dev)
+        t_h1 = torch.zeros(Bt, E, dtype=torch.float16, device=dev)
+        t_h2 = torch.zeros(Bt, E, dtype=torch.float16, device=dev)
+        st.temb_all = torch.zeros(Bt, self.temb_total, dtype=torch.float32, device=dev)
+        add(ops.timestep_embed(st.in_t, t_sin, N=Bt, dim=c0))
+        add(ops.skinny_linear(t_sin, W["time_embedding.linear_1.w"], W["time_embedding.linear_1.b"], t_h1, M=Bt, K=c0,
+                              Nout=E, silu_out=True))
+        add(ops.skinny_linear(t_h1, W["time_embedding.linear_2.w"], W["time_embedding.linear_2.b"], t_h2, M=Bt, K=E,
+                              Nout=E, silu_out=True))   # only silu(emb) is ever consumed (resnet.py:238)
+        add(ops.skinny_linear(t_h2, W["temb_all.w"], W["temb_all.b"], st.temb_all, M=Bt, K=E, Nout=self.temb_total))
+
+        # ---- text K / V^T for all cross-attention layers (two GEMMs)
+        st.text_len = 77
+        st.text_k = torch.zeros(Bt * TEXT_PAD, self.text_total, dtype=torch.float16, device=dev)
+        st.text_vt = torch.zeros(Bt, self.text_total, TEXT_PAD, dtype=torch.float16, device=dev)
+        D = cfg.cross_attention_dim
+        add(ops.igemm(st.in_enc, W["text_k.w"], st.text_k, M=Bt * TEXT_PAD, Nout=self.text_total, C1=D, ldx1=self.text_kp,
+                      CinP=self.text_kp, ldo=self.text_total))
+        add(ops.igemm(W["text_v.w"], st.in_enc, st.text_vt, M=self.text_total, Nout=TEXT_PAD, C1=D, ldx1=self.text_kp,
+                      CinP=self.text_kp, ldo=TEXT_PAD, batch=Bt, sx1=0, sw=TEXT_PAD * self.text_kp,
+                      so=self.text_total * TEXT_PAD))
+
+        # ---- input: NCHW latents -> channels-last (padded to 8 channels), conv_in + depth mapping network
+        x_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
+        d_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
+        add(ops.nchw_to_nhwc(st.in_sample, x_in.buf, B=B, C=cfg.in_channels, HW=h * w, Cpad=8))
+        add(ops.nchw_to_nhwc(st.in_depth, d_in.buf, B=B, C=cfg.in_channels, HW=h * w, Cpad=8))
+        x0 = conv3(x_in, "conv_in")
+        e = conv3(d_in, "flow_conv_in.conv_in", epi=2)
+        for i in range(self.n_map_blocks):
+            e2 = conv3(e, f"flow_conv_in.blocks.{i}", epi=2)
+            free(e)
+            e = e2
+        x = conv3(e, "flow_conv_in.conv_out", res=x0)     # depth embedding + conv_in(sample) (:523-526)
+        free(e); free(x0); free(x_in); free(d_in)
+
+        skips = [x]
+        mm = 0
+        nl = cfg.num_levels
+        for i in range(nl):
+            for j in range(cfg.layers_per_block):
+                x2 = resnet(x, f"down_blocks.{i}.resnets.{j}")
+                if x is not skips[-1]:
+                    free(x)
+                x = x2
+                if i != nl - 1:
+                    x2 = spatial(x, f"down_blocks.{i}.attentions.{j}")
+                    free(x)
+                    x = x2
+                x2 = motion(x, f"down_blocks.{i}.motion_modules.{j}", mm)
+                free(x)
+                x = x2
+                mm += 2
+                skips.append(x)
+            if i != nl - 1:
+                x = conv3(x, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+                skips.append(x)
+        x2 = resnet(x, "mid_block.resnets.0")          # x is still referenced by skips[-1]
+        x = x2
+        x2 = spatial(x, "mid_block.attentions.0"); free(x); x = x2
+        x2 = resnet(x, "mid_block.resnets.1"); free(x); x = x2
+        for i in range(nl):
+            for j in range(cfg.layers_per_block + 1):
+                sk = skips.pop()
+                x2 = resnet(x, f"up_blocks.{i}.resnets.{j}", skip=sk)
+                free(x); free(sk)
+                x = x2
+                if i != 0:
+                    x2 = spatial(x, f"up_blocks.{i}.attentions.{j}"); free(x); x = x2
+                x2 = motion(x, f"up_blocks.{i}.motion_modules.{j}", mm); free(x); x = x2
+                mm += 2
+            if i != nl - 1:
+                x2 = conv3(x, f"up_blocks.{i}.upsamplers.0.conv", ups=1); free(x); x = x2
+        hn = gn(x, "conv_norm_out", cfg.norm_eps, True)
+        free(x)
+        y = conv3(hn, "conv_out")
+        add(ops.nhwc_to_nchw(y.buf, st.out_sample, B=B, C=cfg.out_channels, HW=h * w, ld=cfg.out_channels))
+        st.kv_ptrs = [c.data_ptr() for c in kv_cache]
+        st.arena_bytes = ar.nbytes()
+        st.n_ops = len(pl)
+        return st
+
+    def _plan(self, mode, kv_cache):
+        st = self._plans.get(mode)
+        if st is None:
+            st = self._build_plan(mode, kv_cache)
+            self._plans[mode] = st
+        return st
+
+    def _bind_caches(self, st, kv_cache, row: Optional[int] = None):
+        """Re-point the temporal-attention ops at the caller's cache tensors (they normally never change:
+        the pipeline owns one `kv_cache_list` for the stream's lifetime)."""
+        changed = False
+        for tag, idx in st.tattn_ops:
+            c = kv_cache[idx]
+            assert c.dtype == torch.float16 and c.is_contiguous(), "kv_cache must be contiguous fp16 [N,2,T,L,C]"
+            ptr = c.data_ptr() if row is None else c.data_ptr() + row * c.stride(0) * 2
+            op = st.pl[tag]
+            if op.p[1] != ptr:
+                op.p[1] = ptr
+                changed = True
+        if changed:
+            st.pl._arr = None
+            self._graph.pop(st.mode, None)
+
+    def _run(self, st):
+        if self.use_graph:
+            g = self._graph.get(st.mode)
+            if g is None:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g = _lib.Graph(st.pl, stream=int(side.cuda_stream))
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph[st.mode] = g
+            g.launch()
+        else:
+            st.pl.run()
+
+    # ------------------------------------------------------------------ the boundary call
+    @torch.no_grad()
+    def __call__(self, sample, timestep, encoder_hidden_states=None, temporal_attention_mask=None, depth_sample=None,
+                 kv_cache=None, pe_idx=None, update_idx=None, return_dict: bool = True, **kwargs):
+        N, cfg = self.N, self.cfg
+        if tuple(sample.shape) != (N, cfg.in_channels, 1, self.h, self.w):
+            raise ValueError(f"sample shape {tuple(sample.shape)} != static {(N, cfg.in_channels, 1, self.h, self.w)}")
+        if kv_cache is None or len(kv_cache) != len(self.mm_layout):
+            raise ValueError(f"kv_cache must be the list of {len(self.mm_layout)} caches from prepare_cache()")
+        if encoder_hidden_states.shape[1] != 77 and encoder_hidden_states.shape[1] > TEXT_PAD:
+            raise ValueError("encoder_hidden_states: at most 80 tokens supported")
+        st = self._plan("stream", kv_cache)
+        self._bind_caches(st, kv_cache)
+        st.text_len_rt = encoder_hidden_states.shape[1]
+        if st.text_len_rt != st.text_len:
+            raise ValueError(f"text length {st.text_len_rt} != static {st.text_len}")
+        st.in_sample.copy_(sample.reshape(N, cfg.in_channels, -1))
+        st.in_depth.copy_(depth_sample.reshape(N, cfg.in_channels, -1))
+        st.in_t.copy_(timestep.reshape(-1).expand(N))
+        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(encoder_hidden_states)
+        st.in_bias.copy_(temporal_attention_mask)
+        st.in_pe_idx.copy_(pe_idx)
+        st.in_upd.copy_(update_idx)
+        self._run(st)
+        out = st.out_sample.view(N, cfg.out_channels, 1, self.h, self.w)
+        if not return_dict:
+            return (out, kv_cache)
+        return UNetOutput(out, kv_cache)
+
+    @torch.no_grad()
+    def warmup(self, sample, timestep, encoder_hidden_states=None, depth_sample=None, kv_cache=None, row: int = 0,
+               return_dict: bool = True, **kwargs):
+        """Warm-up UNet pass over F frames that fills cache row `row` (slots 0..F-1) of every layer.
+        sample/depth [1,4,F,h,w]; timestep [1]; encoder_hidden_states [1,77,D]; kv_cache = the FULL cache list
+        (the reference passes `[cache[idx] for cache in kv_cache_list]`, pipeline :326)."""
+        F_, cfg = self.F, self.cfg
+        if tuple(sample.shape) != (1, cfg.in_channels, F_, self.h, self.w):
+            raise ValueError(f"warm-up sample shape {tuple(sample.shape)} != {(1, cfg.in_channels, F_, self.h, self.w)}")
+        st = self._plan("warmup", kv_cache)
+        self._bind_caches(st, kv_cache, row=row)
+        st.in_sample.copy_(sample[0].transpose(0, 1).reshape(F_, cfg.in_channels, -1))
+        st.in_depth.copy_(depth_sample[0].transpose(0, 1).reshape(F_, cfg.in_channels, -1))
+        st.in_t.copy_(timestep.reshape(-1)[:1])
+        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(encoder_hidden_states[:1])
+        self._run(st)
+        out = st.out_sample.view(F_, cfg.out_channels, self.h, self.w).transpose(0, 1).unsqueeze(0)
+        if not return_dict:
+            return (out,)
+        return UNetOutput(out, kv_cache)
+
+    # ------------------------------------------------------------------ introspection for bench / tests
+    def plan_summary(self, mode="stream"):
+        st = self._plans[mode]
+        kinds = {}
+        for j in range(len(st.pl)):
+            kinds[st.pl[j].kind] = kinds.get(st.pl[j].kind, 0) + 1
+        return dict(n_ops=len(st.pl), kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())

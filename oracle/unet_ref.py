@@ -150,39 +150,51 @@ def spatial_transformer(x, enc, w: _W, cfg):
     return y + res
 
 
-def stream_temporal_attention(x, w: _W, cfg, cache, bias, pe_idx, update_idx, pe):
-    """reference stream_motion_module.py:99-213.
-    x [N,T,C] (layer-normed tokens), cache [N,2,T,L,C] MUTATED IN PLACE (pre-PE projections),
-    bias [N,L] additive (0/-inf), pe_idx [N,L] int64, update_idx [N] int64, pe [max_len,C]."""
-    n, t, c = x.shape
+def stream_temporal_core(q, k, v, w: _W, cfg, cache, bias, pe_idx, update_idx, pe):
+    """The cache/PE/softmax core of reference stream_motion_module.py:112-194 on already projected
+    q,k,v [N,T,C]: returns the attention output BEFORE to_out.  cache [N,2,T,L,C] is mutated in place."""
+    n, t, c = q.shape
     L = cfg.window_size
-    q, k, v = _lin(x, w, "to_q"), _lin(x, w, "to_k"), _lin(x, w, "to_v")
     for i in range(n):                                  # :117-119
         cache[i, 0, :, update_idx[i]] = k[i].to(cache.dtype)
         cache[i, 1, :, update_idx[i]] = v[i].to(cache.dtype)
     pe_l = pe[:L]                                       # prepare_pe_buffer :79-97
     q_pe, k_pe, v_pe = (F.linear(pe_l, w(nm + ".weight")) for nm in ("to_q", "to_k", "to_v"))
     q_idx = torch.stack([pe_idx[i, update_idx[i]] for i in range(n)])       # :125-127
-    qf = q + q_pe[q_idx][:, None, :]                                        # :139
+    qf = q.float() + q_pe[q_idx][:, None, :]                                # :139
     kf = cache[:, 0].float() + k_pe[pe_idx][:, None]                        # :140  [N,T,L,C]
     vf = cache[:, 1].float() + v_pe[pe_idx][:, None]                        # :141
     o = _mha(qf[:, :, None, :], kf, vf, cfg.temporal_heads, bias=bias.float()[:, None, None, None, :])
-    return _lin(o[:, :, 0, :], w, "to_out.0")
+    return o[:, :, 0, :]
+
+
+def stream_temporal_attention(x, w: _W, cfg, cache, bias, pe_idx, update_idx, pe):
+    """reference stream_motion_module.py:99-213.
+    x [N,T,C] (layer-normed tokens), cache [N,2,T,L,C] MUTATED IN PLACE (pre-PE projections),
+    bias [N,L] additive (0/-inf), pe_idx [N,L] int64, update_idx [N] int64, pe [max_len,C]."""
+    q, k, v = _lin(x, w, "to_q"), _lin(x, w, "to_k"), _lin(x, w, "to_v")
+    o = stream_temporal_core(q, k, v, w, cfg, cache, bias, pe_idx, update_idx, pe)
+    return _lin(o, w, "to_out.0")
+
+
+def warmup_temporal_core(q, k, v, w: _W, cfg, cache_row, pe):
+    """Core of reference motion_module.py:492-510 on projected q,k,v [T,F,C] (per pixel sequences)."""
+    f = q.shape[1]
+    cache_row[0, :, :f, :] = k.to(cache_row.dtype)       # :492-493
+    cache_row[1, :, :f, :] = v.to(cache_row.dtype)
+    pe_f = pe[:f]
+    q = q.float() + F.linear(pe_f, w("to_q.weight"))
+    k = k.float() + F.linear(pe_f, w("to_k.weight"))
+    v = v.float() + F.linear(pe_f, w("to_v.weight"))
+    return _mha(q, k, v, cfg.temporal_heads)
 
 
 def warmup_temporal_attention(x, w: _W, cfg, cache_row, pe):
     """reference motion_module.py:469-530 (VersatileAttention, no mask).
     x [F,T,C] warm-up frames; cache_row [2,T,L,C]: slots 0..F-1 receive the pre-PE K / V."""
-    f, t, c = x.shape
     xt = x.transpose(0, 1)                               # "(b f) d c -> (b d) f c"  [T,F,C]
     q, k, v = _lin(xt, w, "to_q"), _lin(xt, w, "to_k"), _lin(xt, w, "to_v")
-    cache_row[0, :, :f, :] = k.to(cache_row.dtype)       # :492-493
-    cache_row[1, :, :f, :] = v.to(cache_row.dtype)
-    pe_f = pe[:f]
-    q = q + F.linear(pe_f, w("to_q.weight"))
-    k = k + F.linear(pe_f, w("to_k.weight"))
-    v = v + F.linear(pe_f, w("to_v.weight"))
-    o = _mha(q, k, v, cfg.temporal_heads)
+    o = warmup_temporal_core(q, k, v, w, cfg, cache_row, pe)
     return _lin(o, w, "to_out.0").transpose(0, 1)
 
 

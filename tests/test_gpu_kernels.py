@@ -1,0 +1,354 @@
+"""-m gpu: every HIP kernel, called through the C ABI (libl2d_hip.so), against fp32 references.
+
+Tolerances (fp16 storage, fp32 accumulate): per-op rel-L2 <= 2e-3 against the fp32 reference evaluated on the
+SAME fp16-rounded inputs.  Nothing here reads /root/reference.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def check(a, b, tol=2e-3, what=""):
+    assert torch.isfinite(a.float()).all(), f"{what}: non-finite output"
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel-L2 {e:.3e} > {tol:.1e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from live2diff_amd import _lib, ops
+    print("device:", _lib.device_name())
+    return ops
+
+
+# ----------------------------------------------------------------------------- igemm: linear
+@pytest.mark.parametrize("M,K,N", [(128, 64, 128), (8192, 320, 640), (300, 96, 68), (154, 768, 1280), (2048, 1280, 1280),
+                                   (77, 320, 4), (512, 2560, 320)])
+def test_igemm_linear(L, M, K, N):
+    x = rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3).float()
+    r = rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t() + b + r.float()
+    wp = L.pack_linear(w.to(DEV))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, CinP=wp.shape[1], ldo=N, bias=b.to(DEV), res=r.to(DEV), ldr=N))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"linear {M}x{K}x{N}")
+
+
+def test_igemm_geglu(L):
+    M, C = 300, 64
+    x = rnd(M, C, seed=1)
+    w = rnd(8 * C, C, seed=2, scale=C ** -0.5)
+    b = rnd(8 * C, seed=3)
+    hg = x.float() @ w.float().t() + b.float()
+    ref = hg[:, :4 * C] * F.gelu(hg[:, 4 * C:])
+    wp, bp = L.pack_geglu(w.to(DEV), b.to(DEV))
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=8 * C, C1=C, ldx1=C, CinP=wp.shape[1], ldo=4 * C, bias=bp, epi=1))
+    torch.cuda.synchronize()
+    check(out, ref, what="geglu")
+    # big-tile path
+    M, C = 4096, 320
+    x = rnd(M, C, seed=5)
+    w = rnd(8 * C, C, seed=6, scale=C ** -0.5)
+    b = rnd(8 * C, seed=7)
+    hg = x.float() @ w.float().t() + b.float()
+    ref = hg[:, :4 * C] * F.gelu(hg[:, 4 * C:])
+    wp, bp = L.pack_geglu(w.to(DEV), b.to(DEV))
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=8 * C, C1=C, ldx1=C, CinP=wp.shape[1], ldo=4 * C, bias=bp, epi=1))
+    torch.cuda.synchronize()
+    check(out, ref, what="geglu big")
+
+
+def test_igemm_concat_linear(L):
+    M, C1, C2, N = 520, 128, 64, 96
+    x1, x2 = rnd(M, C1, seed=1), rnd(M, C2, seed=2)
+    w = rnd(N, C1 + C2, seed=3, scale=(C1 + C2) ** -0.5)
+    ref = torch.cat([x1, x2], 1).float() @ w.float().t()
+    wp = L.pack_linear(w.to(DEV))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    L.run(L.igemm(x1.to(DEV), wp, out, M=M, Nout=N, C1=C1, ldx1=C1, CinP=wp.shape[1], ldo=N, x2=x2.to(DEV), C2=C2, ldx2=C2))
+    torch.cuda.synchronize()
+    check(out, ref, what="concat linear")
+
+
+def test_igemm_swapped_batched(L):
+    """V^T[b] = Wv . X[b]^T (operand roles swapped, batch over grid.z)"""
+    B, T, C = 2, 260, 128
+    x = rnd(B, T, C, seed=1)
+    wv = rnd(C, C, seed=2, scale=C ** -0.5)
+    ref = torch.einsum("ck,btk->bct", wv.float(), x.float())
+    ld = (T + 7) // 8 * 8
+    out = torch.zeros(B, C, ld, dtype=torch.float16, device=DEV)
+    wp = L.pack_linear(wv.to(DEV))
+    L.run(L.igemm(wp, x.to(DEV), out, M=C, Nout=T, C1=C, ldx1=wp.shape[1], CinP=C, ldo=ld, batch=B, sx1=0, sw=T * C, so=C * ld))
+    torch.cuda.synchronize()
+    check(out[:, :, :T], ref, what="swapped batched")
+
+
+# ----------------------------------------------------------------------------- igemm: conv
+@pytest.mark.parametrize("cin,cout,H,W,stride,ups", [(64, 64, 8, 8, 1, 0), (8, 64, 12, 10, 1, 0), (96, 64, 9, 7, 1, 0),
+                                                     (64, 128, 12, 10, 2, 0), (64, 64, 5, 6, 1, 1), (320, 320, 32, 32, 1, 0),
+                                                     (16, 16, 8, 8, 1, 0), (320, 4, 16, 16, 1, 0)])
+def test_igemm_conv3x3(L, cin, cout, H, W, stride, ups):
+    B = 2
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rnd(cout, seed=3).float()
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    xl = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = L.pack_conv3x3(w.to(DEV))
+    out = torch.empty(B * Ho * Wo, cout, dtype=torch.float16, device=DEV)
+    L.run(L.igemm(xl, wp, out, M=B * Ho * Wo, Nout=cout, C1=cin, ldx1=cin, CinP=wp.shape[1] // 9, ldo=cout, bias=b.to(DEV),
+                  taps=9, B=B, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups))
+    torch.cuda.synchronize()
+    check(out.view(B, Ho, Wo, cout).permute(0, 3, 1, 2), ref, what=f"conv {cin}->{cout} s{stride} u{ups}")
+
+
+def test_igemm_conv_rowbias_res_silu(L):
+    B, cin, cout, H, W = 3, 64, 64, 6, 5
+    x = rnd(B, cin, H, W, seed=1)
+    w = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    b = rnd(cout, seed=3).float()
+    rb = rnd(B, 200, seed=4).float()
+    off = 72
+    res = rnd(B, cout, H, W, seed=5)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1) + rb[:, off:off + cout, None, None] + res.float()
+    wp = L.pack_conv3x3(w.to(DEV))
+    out = torch.empty(B * H * W, cout, dtype=torch.float16, device=DEV)
+    rbd = rb.to(DEV)
+    opk = L.igemm(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp, out, M=B * H * W, Nout=cout, C1=cin, ldx1=cin,
+                  CinP=wp.shape[1] // 9, ldo=cout, bias=b.to(DEV), rowbias=rbd, ldrb=200, rows_per_bias=H * W,
+                  res=res.permute(0, 2, 3, 1).contiguous().to(DEV), ldr=cout, taps=9, B=B, Hin=H, Win=W, Hout=H, Wout=W)
+    opk[0].p[4] = rbd.data_ptr() + 4 * off
+    L.run(opk)
+    torch.cuda.synchronize()
+    check(out.view(B, H, W, cout).permute(0, 3, 1, 2), ref, what="conv rowbias+res")
+    ref2 = F.silu(F.conv2d(x.float(), w.float(), b, padding=1))
+    L.run(L.igemm(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp, out, M=B * H * W, Nout=cout, C1=cin, ldx1=cin,
+                  CinP=wp.shape[1] // 9, ldo=cout, bias=b.to(DEV), taps=9, B=B, Hin=H, Win=W, Hout=H, Wout=W, epi=2))
+    torch.cuda.synchronize()
+    check(out.view(B, H, W, cout).permute(0, 3, 1, 2), ref2, what="conv silu")
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C1,C2,T,silu", [(64, 0, 16, True), (320, 0, 4096, True), (640, 320, 1024, True), (1280, 640, 256, False),
+                                          (1280, 1280, 64, True), (128, 64, 300, False)])
+def test_groupnorm(L, C1, C2, T, silu):
+    B, G, eps = 2, 32, 1e-5
+    C = C1 + C2
+    x1 = rnd(B, T, C1, seed=1) + 0.5
+    x2 = rnd(B, T, C2, seed=2) * 2 if C2 else None
+    gm, bt = (1 + 0.1 * rnd(C, seed=3).float()).half(), (0.1 * rnd(C, seed=4).float()).half()
+    xc = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(xc.float().permute(0, 2, 1), G, gm.float(), bt.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    nchunk = max(1, min(32, T // 64))
+    partial = torch.empty(B * nchunk * G * 2, dtype=torch.float32, device=DEV)
+    out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
+    kw = dict(B=B, T=T, C1=C1, ld1=C1, G=G, nchunk=nchunk, x2=(x2.to(DEV) if C2 else None), C2=C2, ld2=C2)
+    x1d = x1.to(DEV)
+    L.run(L.gn_stats(x1d, partial, **kw))
+    L.run(L.gn_apply(x1d, partial, gm.to(DEV), bt.to(DEV), out, eps=eps, silu=silu, **kw))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"groupnorm {C1}+{C2} T{T}")
+
+
+@pytest.mark.parametrize("rows,C", [(7, 64), (8192, 320), (100, 1280), (33, 640)])
+def test_layernorm(L, rows, C):
+    x = rnd(rows, C, seed=1) * 3 + 1
+    gm, bt = (1 + 0.1 * rnd(C, seed=3).float()).half(), (0.1 * rnd(C, seed=4).float()).half()
+    ref = F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5)
+    out = torch.empty(rows, C, dtype=torch.float16, device=DEV)
+    L.run(L.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), out, rows=rows, C=C, ldx=C, ldo=C))
+    torch.cuda.synchronize()
+    check(out, ref, what="layernorm")
+
+
+# ----------------------------------------------------------------------------- flash attention
+@pytest.mark.parametrize("d,Tq,Tk", [(8, 256, 256), (16, 64, 64), (32, 100, 77), (40, 1024, 1024), (40, 4096, 77),
+                                     (80, 1024, 1024), (160, 256, 256), (160, 64, 77), (40, 130, 200), (80, 144, 144)])
+def test_flash_attn(L, d, Tq, Tk):
+    B, H = 2, 8
+    C = H * d
+    q, k, v = rnd(B, Tq, C, seed=1), rnd(B, Tk, C, seed=2), rnd(B, Tk, C, seed=3)
+    qh, kh, vh = (t.float().view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Tq, C)
+    ldvt = (Tk + 7) // 8 * 8
+    vt = torch.full((B, C, ldvt), float("nan"), dtype=torch.float16)     # padding columns hold garbage
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    out = torch.empty(B, Tq, C, dtype=torch.float16, device=DEV)
+    L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=Tq, Tk=Tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
+                       sq=Tq * C, sk=Tk * C, svt=C * ldvt, so=Tq * C))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"flash d{d} {Tq}x{Tk}")
+
+
+def test_flash_attn_softmax_stress(L):
+    """large logits + one dominant key per row: exercises the running-max rescale across tiles"""
+    B, H, d, T = 1, 8, 40, 512
+    C = H * d
+    q, k, v = rnd(B, T, C, seed=1) * 4, rnd(B, T, C, seed=2) * 4, rnd(B, T, C, seed=3)
+    k[:, 300] *= 3
+    qh, kh, vh = (t.float().view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, T, C)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
+    L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C,
+                       sq=T * C, sk=T * C, svt=C * T, so=T * C))
+    torch.cuda.synchronize()
+    check(out, ref, tol=4e-3, what="flash stress")
+
+
+# ----------------------------------------------------------------------------- temporal attention
+def _tattn_case(C, T, Lw, S, N, seed, ramp=True):
+    g = torch.Generator().manual_seed(seed)
+    pe_idx = torch.stack([torch.cat([torch.arange(S), S + torch.randperm(Lw - S, generator=g)]) for _ in range(N)])
+    upd = torch.randint(S, Lw, (N,), generator=g)
+    bias = torch.zeros(N, Lw)
+    if ramp:
+        for n in range(N):
+            if n % 2 == 1:
+                bias[n, S + 2:] = float("-inf")
+    return pe_idx, upd, bias
+
+
+@pytest.mark.parametrize("C,T,Lw,S,N,variant", [(64, 16, 16, 8, 2, 0), (64, 50, 12, 4, 1, 0), (128, 8, 24, 8, 4, 0),
+                                                (64, 4, 40, 8, 2, 0), (320, 256, 16, 8, 2, 0), (320, 256, 16, 8, 2, 2),
+                                                (320, 100, 16, 8, 2, 3), (640, 64, 16, 8, 2, 0), (1280, 16, 16, 8, 2, 0),
+                                                (1280, 64, 40, 8, 2, 0), (256, 37, 24, 8, 3, 0)])
+def test_tattn_stream(L, C, T, Lw, S, N, variant):
+    from live2diff_amd.config import tiny_config
+    from oracle import unet_ref as O
+    cfg = tiny_config(window_size=Lw, sink_size=S)
+    pe_idx, upd, bias = _tattn_case(C, T, Lw, S, N, seed=7)
+    q, k, v = rnd(N, T, C, seed=1), rnd(N, T, C, seed=2), rnd(N, T, C, seed=3)
+    cache0 = rnd(N, 2, T, Lw, C, seed=4)
+    sd = {f"to_{n}.weight": rnd(C, C, seed=10 + i, scale=C ** -0.5) for i, n in enumerate("qkv")}
+    pe = O.sinusoid_pe(max(24, Lw), C)
+    tabs = [(pe[:Lw] @ sd[f"to_{n}.weight"].float().t()).half() for n in "qkv"]
+    # the reference's tables are fp16 buffers: the oracle core sees the fp16-rounded tables via an identity "weight"
+    cache_ref = cache0.clone().float()
+    w_ = O._W({k_: v_.float() for k_, v_ in sd.items()})
+    ref = O.stream_temporal_core(q.float(), k.float(), v.float(), w_, cfg, cache_ref, bias, pe_idx, upd, pe)
+    qkv = torch.cat([q, k, v], -1).reshape(N * T, 3 * C).contiguous().to(DEV)
+    cache = cache0.clone().to(DEV)
+    out = torch.empty(N * T, C, dtype=torch.float16, device=DEV)
+    L.run(L.tattn_stream(qkv, cache, tabs[0].to(DEV), tabs[1].to(DEV), tabs[2].to(DEV), pe_idx.to(DEV), upd.to(DEV),
+                         bias.half().to(DEV), out, N=N, T=T, C=C, L=Lw, H=8, variant=variant))
+    torch.cuda.synchronize()
+    check(out.view(N, T, C), ref, tol=3e-3, what=f"tattn_stream C{C} L{Lw} v{variant}")
+    # cache: exactly slot update_idx[n] of row n rewritten with the (pre-PE) k / v, everything else untouched
+    assert torch.equal(cache.cpu(), cache_ref.half()), "cache contents differ from the reference update"
+
+
+def test_tattn_stream_golden(L, golden):
+    """directly against the fixture captured from the reference's StreamTemporalAttention (incl. projections
+    done on the host in fp32 -> the kernel sees fp16-rounded q,k,v)."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.weights import _fill
+    from oracle import unet_ref as O
+    for ci in range(4):
+        g = golden(f"stream_attn_{ci}")
+        C, T, Lw, S, N = [int(v) for v in g["meta"]]
+        sd = {k: _fill(f"sta{ci}." + k, shp, 1.0) for k, shp in
+              {"to_q.weight": (C, C), "to_k.weight": (C, C), "to_v.weight": (C, C), "to_out.0.weight": (C, C), "to_out.0.bias": (C,)}.items()}
+        x = torch.from_numpy(g["x"])
+        q, k, v = (x @ sd[f"to_{n}.weight"].t() for n in "qkv")
+        pe = O.sinusoid_pe(max(24, Lw), C)
+        tabs = [(pe[:Lw] @ sd[f"to_{n}.weight"].t()).half().to(DEV) for n in "qkv"]
+        qkv = torch.cat([q, k, v], -1).reshape(N * T, 3 * C).half().contiguous().to(DEV)
+        cache = torch.from_numpy(g["cache_in"]).half().to(DEV)
+        out = torch.empty(N * T, C, dtype=torch.float16, device=DEV)
+        L.run(L.tattn_stream(qkv, cache, *tabs, torch.from_numpy(g["pe_idx"]).to(DEV), torch.from_numpy(g["update_idx"]).to(DEV),
+                             torch.from_numpy(g["bias"]).half().to(DEV), out, N=N, T=T, C=C, L=Lw, H=8))
+        torch.cuda.synchronize()
+        full = out.float().cpu().view(N, T, C) @ sd["to_out.0.weight"].t() + sd["to_out.0.bias"]
+        check(full, torch.from_numpy(g["out"]), tol=5e-3, what=f"golden stream_attn_{ci}")
+        check(cache, torch.from_numpy(g["cache_out"]), tol=1e-3, what=f"golden cache {ci}")
+
+
+@pytest.mark.parametrize("C,T", [(64, 20), (128, 16), (320, 64), (640, 16), (1280, 9), (256, 16)])
+def test_tattn_warmup(L, C, T):
+    from live2diff_amd.config import tiny_config
+    from oracle import unet_ref as O
+    Fr, Lw = 8, 16
+    cfg = tiny_config(window_size=Lw, sink_size=8)
+    q, k, v = rnd(Fr, T, C, seed=1), rnd(Fr, T, C, seed=2), rnd(Fr, T, C, seed=3)
+    sd = {f"to_{n}.weight": rnd(C, C, seed=10 + i, scale=C ** -0.5) for i, n in enumerate("qkv")}
+    pe = O.sinusoid_pe(24, C)
+    tabs = [(pe[:Lw] @ sd[f"to_{n}.weight"].float().t()).half() for n in "qkv"]
+    row_ref = torch.zeros(2, T, Lw, C)
+    w_ = O._W({k_: v_.float() for k_, v_ in sd.items()})
+    ref = O.warmup_temporal_core(q.float().transpose(0, 1), k.float().transpose(0, 1), v.float().transpose(0, 1), w_, cfg,
+                                 row_ref, pe).transpose(0, 1)
+    qkv = torch.cat([q, k, v], -1).reshape(Fr * T, 3 * C).contiguous().to(DEV)
+    row = torch.zeros(2, T, Lw, C, dtype=torch.float16, device=DEV)
+    out = torch.empty(Fr * T, C, dtype=torch.float16, device=DEV)
+    L.run(L.tattn_warmup(qkv, row, tabs[0].to(DEV), tabs[1].to(DEV), tabs[2].to(DEV), out, F=Fr, T=T, C=C, L=Lw, H=8))
+    torch.cuda.synchronize()
+    check(out.view(Fr, T, C), ref, tol=3e-3, what=f"tattn_warmup C{C}")
+    assert torch.equal(row.cpu(), row_ref.half())
+
+
+# ----------------------------------------------------------------------------- small kernels
+def test_timestep_and_skinny(L):
+    from oracle import unet_ref as O
+    t = torch.tensor([399, 199, 999, 0], dtype=torch.int64)
+    out = torch.empty(4, 320, dtype=torch.float16, device=DEV)
+    L.run(L.timestep_embed(t.to(DEV), out, N=4, dim=320))
+    torch.cuda.synchronize()
+    ref = O.timestep_sinusoid(t, 320)
+    assert (out.float().cpu() - ref).abs().max() < 2e-3
+    for M, K, N, silu, isf in [(2, 320, 1280, True, False), (4, 1280, 1000, False, True), (1, 64, 7, False, False), (8, 1280, 64, True, True)]:
+        a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3).float()
+        ref = a.float() @ w.float().t() + b
+        if silu:
+            ref = F.silu(ref)
+        o = torch.empty(M, N, dtype=torch.float32 if isf else torch.float16, device=DEV)
+        L.run(L.skinny_linear(a.to(DEV), w.to(DEV), b.to(DEV), o, M=M, K=K, Nout=N, silu_out=silu))
+        torch.cuda.synchronize()
+        check(o, ref, what=f"skinny {M}x{K}x{N}")
+
+
+def test_layout_and_lcm(L, golden):
+    x = rnd(3, 4, 35, seed=1)
+    o = torch.empty(3, 35, 8, dtype=torch.float16, device=DEV)
+    L.run(L.nchw_to_nhwc(x.to(DEV), o, B=3, C=4, HW=35, Cpad=8))
+    torch.cuda.synchronize()
+    assert torch.equal(o[:, :, :4].cpu(), x.transpose(1, 2)) and (o[:, :, 4:] == 0).all()
+    y = rnd(3, 35, 4, seed=2)
+    o2 = torch.empty(3, 4, 35, dtype=torch.float16, device=DEV)
+    L.run(L.nhwc_to_nchw(y.to(DEV), o2, B=3, C=4, HW=35, ld=4))
+    torch.cuda.synchronize()
+    assert torch.equal(o2.cpu(), y.transpose(1, 2))
+    g = golden("state_machine")
+    xs, eps = torch.from_numpy(g["lcm_x"]).half(), torch.from_numpy(g["lcm_eps"]).half()
+    scal = torch.stack([torch.from_numpy(g[k]).flatten() for k in ("lcm_alpha", "lcm_beta", "lcm_c_skip", "lcm_c_out")], 1).float()
+    x0 = torch.empty_like(xs, device=DEV)
+    L.run(L.lcm_step(xs.to(DEV), eps.to(DEV), scal.contiguous().to(DEV), x0, N=3, per=xs[0].numel()))
+    torch.cuda.synchronize()
+    check(x0, torch.from_numpy(g["lcm_x0"]), tol=3e-3, what="lcm step")

@@ -1,0 +1,112 @@
+"""-m gpu: the full HIP streaming UNet (boundary object `HipStreamingUNet`) against the fp32 oracle on the
+same key-hashed weights and seeded inputs: N warm-up passes (cache fill) then streaming frames driven by the
+reference's ring-buffer trace (tests/golden/state_machine.npz).
+
+Tolerance (stated): eps-prediction rel-L2 <= 1e-2 and cosine >= 0.9995 per frame, fp16
+kernels vs fp32 oracle; KV-cache rel-L2 <= 5e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def cos(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm())).item()
+
+
+def rnd(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def _rollout(cfg, h, w, N, frames, golden, use_graph=False, gain=1.0):
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    from oracle import unet_ref as O
+
+    sm = golden("state_machine")
+    sd = random_state_dict(cfg, dtype=torch.float16, gain=gain)           # both sides see the fp16-rounded weights
+    sd32 = {k: v.float() for k, v in sd.items()}
+    unet = HipStreamingUNet({k: v.to(DEV) for k, v in sd.items()}, cfg, h, w, N, use_graph=use_graph)
+    kv = unet.prepare_cache(N)
+    kv_ref = O.alloc_kv_cache(cfg, h, w, N)
+    D = cfg.cross_attention_dim
+    enc = rnd(1, 77, D, seed=700).half()
+    ts = torch.tensor([399, 199, 99, 19][:N])
+    F_ = cfg.sink_size
+    wx, wd = rnd(N, 4, F_, h, w, seed=701).half(), rnd(1, 4, F_, h, w, seed=702).half()
+    report = []
+    for idx in range(N):
+        ref = O.unet_forward(sd32, cfg, wx[idx:idx + 1].float(), ts[idx:idx + 1], enc.float(), wd.float(), kv_ref,
+                             mode="warmup", warmup_row=idx)
+        out = unet.warmup(wx[idx:idx + 1].to(DEV), ts[idx:idx + 1].to(DEV), encoder_hidden_states=enc.to(DEV),
+                          depth_sample=wd.to(DEV), kv_cache=kv, row=idx)["sample"]
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        report.append(("warmup", idx, rel(out, ref), cos(out, ref)))
+    kvr = max(rel(a, b) for a, b in zip(kv, kv_ref))
+    report.append(("cache-after-warmup", 0, kvr, 1.0))
+    key = f"n{N}"
+    for f in range(frames):
+        x, d = rnd(N, 4, 1, h, w, seed=800 + f).half(), rnd(N, 4, 1, h, w, seed=900 + f).half()
+        bias = torch.from_numpy(sm["bias_" + key])[f]
+        pe_idx = torch.from_numpy(sm["pe_idx_" + key])[f]
+        upd = torch.from_numpy(sm["update_idx_" + key])[f]
+        ref = O.unet_forward(sd32, cfg, x.float(), ts, enc.float().repeat(N, 1, 1), d.float(), kv_ref,
+                             temporal_attention_mask=bias, pe_idx=pe_idx, update_idx=upd)
+        o = unet(x.to(DEV), ts.to(DEV), encoder_hidden_states=enc.repeat(N, 1, 1).to(DEV),
+                 temporal_attention_mask=bias.half().to(DEV), depth_sample=d.to(DEV), kv_cache=kv, pe_idx=pe_idx.to(DEV),
+                 update_idx=upd.to(DEV))
+        assert o["kv_cache"] is kv
+        out = o["sample"]
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        report.append(("stream", f, rel(out, ref), cos(out, ref)))
+    kvr = max(rel(a, b) for a, b in zip(kv, kv_ref))
+    report.append(("cache-final", 0, kvr, 1.0))
+    return report, unet
+
+
+def _assert(report):
+    for what, i, r, c in report:
+        print(f"{what:>20s} {i:3d}  rel-L2 {r:.3e}  cos {c:.6f}")
+    for what, i, r, c in report:
+        if what.startswith("cache"):
+            assert r <= 5e-3, (what, i, r)
+        else:
+            assert r <= 1e-2 and c >= 0.9995, (what, i, r, c)
+
+
+def test_tiny_unet_rollout(golden):
+    from live2diff_amd.config import tiny_config
+    cfg = tiny_config(channels=(64, 128, 256, 256), cross_attention_dim=96)
+    report, unet = _rollout(cfg, 16, 16, 2, 10, golden)
+    print(unet.plan_summary())
+    _assert(report)
+
+
+def test_tiny_unet_rollout_n3_graph(golden):
+    """3 denoising steps, non-square latent, hipGraph replay of the plan."""
+    from live2diff_amd.config import tiny_config
+    cfg = tiny_config(channels=(64, 128, 256, 256), cross_attention_dim=64)
+    report, _ = _rollout(cfg, 16, 24, 3, 10, golden, use_graph=True)
+    _assert(report)
+
+
+def test_sd15_width_single_step(golden):
+    """Real SD-1.5 widths (320/640/1280/1280, d = 40/80/160) at a 256x256 image (32x32 latent): one warm-up
+    pass per row + 2 streaming frames against the oracle (CPU fp32, ~1 min)."""
+    from live2diff_amd.config import sd15_config
+    cfg = sd15_config()
+    report, unet = _rollout(cfg, 32, 32, 2, 2, golden)
+    print(unet.plan_summary())
+    _assert(report)

@@ -1,0 +1,161 @@
+"""CPU tests (-m "not gpu"): host-side logic against the reference goldens, and the C-ABI library surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_ring_buffer_trace_matches_reference(golden, n):
+    """40-frame trace of (attn_bias, pe_idx, update_idx) captured from the reference's
+    initialize_attn_bias_pe_and_update_idx / update_attn_bias (pipeline :403-438)."""
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    g = golden("state_machine")
+    b, p, u = ring_buffer_init(n)
+    for f in range(41):
+        assert torch.equal(b, torch.from_numpy(g[f"bias_n{n}"][f])), f
+        assert torch.equal(p, torch.from_numpy(g[f"pe_idx_n{n}"][f])), f
+        assert torch.equal(u, torch.from_numpy(g[f"update_idx_n{n}"][f])), f
+        ring_buffer_update(b, p, u)
+
+
+def test_ring_buffer_general_windows():
+    """N=1 and other sink/window sizes (undefined in the reference): invariants of the steady state."""
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    for n, L, S in [(1, 12, 4), (2, 24, 8), (2, 40, 8), (4, 16, 8)]:
+        b, p, u = ring_buffer_init(n, L, S)
+        for f in range(3 * L):
+            ring_buffer_update(b, p, u, L, S)
+        assert (b == 0).all()
+        for i in range(n):
+            assert sorted(p[i].tolist()) == list(range(L))          # a permutation
+            assert p[i, :S].tolist() == list(range(S))              # sink slots keep PE 0..S-1
+            assert p[i, u[i]] == L - 1 and S <= u[i] < L            # newest frame always gets the largest PE
+
+
+def test_lcm_step_and_add_noise(golden):
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth as S
+    g = golden("state_machine")
+    fake = S.__new__(S)
+    fake.alpha_prod_t_sqrt, fake.beta_prod_t_sqrt = torch.from_numpy(g["lcm_alpha"]), torch.from_numpy(g["lcm_beta"])
+    fake.c_skip, fake.c_out = torch.from_numpy(g["lcm_c_skip"]), torch.from_numpy(g["lcm_c_out"])
+    x, eps = torch.from_numpy(g["lcm_x"]), torch.from_numpy(g["lcm_eps"])
+    assert torch.allclose(S.scheduler_step_batch(fake, eps, x), torch.from_numpy(g["lcm_x0"]), atol=1e-6)
+    assert torch.allclose(S.scheduler_step_batch(fake, eps[1:2], x[1:2], 1), torch.from_numpy(g["lcm_x0_idx1"]), atol=1e-6)
+    assert torch.allclose(S.add_noise(fake, x[1:2], eps[1:2], 1), torch.from_numpy(g["add_noise_1"]), atol=1e-6)
+
+
+def test_lcm_schedule_documented_values():
+    """diffusers-0.25.0 LCMScheduler semantics (stub-pinned): t = 999 - 20 i for 50 steps; demo t_index [30,40]
+    -> [399,199]; boundary scalings at t=399."""
+    from live2diff_amd.scheduler import LCMSchedule
+    s = LCMSchedule()
+    ts = s.set_timesteps(50)
+    assert ts[0] == 999 and ts[30] == 399 and ts[40] == 199 and ts[-1] == 19
+    c_skip, c_out = s.get_scalings_for_boundary_condition_discrete(399)
+    assert abs(float(c_skip) - 0.25 / (3990.0 ** 2 + 0.25)) < 1e-12
+    assert abs(float(c_out) - 3990.0 / (3990.0 ** 2 + 0.25) ** 0.5) < 1e-7
+    assert abs(float(s.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-7
+
+
+def test_param_count_and_layout():
+    from live2diff_amd.config import motion_module_layout, sd15_config
+    from live2diff_amd.weights import count_params
+    cfg = sd15_config()
+    assert count_params(cfg) == 1277745188            # reference classes instantiated at SD-1.5 widths: 1 277.7 M
+    lay = motion_module_layout(cfg, 64, 64)
+    assert len(lay) == 40
+    assert [c for c, *_ in lay[:16]] == [320] * 4 + [640] * 4 + [1280] * 8
+    assert [(hh, ww) for _, hh, ww, _ in lay[16:22]] == [(8, 8)] * 6 and lay[39][:3] == (320, 64, 64)
+    kv_bytes = sum(2 * 2 * hh * ww * 16 * c * 2 for c, hh, ww, _ in lay)
+    assert abs(kv_bytes / 1e9 - 3.04) < 0.02          # 3.04 GB at cfg-2
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly the functions include/l2d.h declares."""
+    from live2diff_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "l2d.h")).read()
+    body = hdr[hdr.index("typedef struct l2d_op"):]
+    names = re.findall(r"\b(l2d_[a-z_]+)\s*\(", body)
+    assert len(names) >= 9
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _lib.lib.l2d_abi_version() == 1
+    assert ctypes.sizeof(_lib.L2dOp) == 232
+    # error path without a device: refused loudly, no fallback
+    ops = (_lib.L2dOp * 1)()
+    ops[0].kind = 99
+    assert _lib.lib.l2d_run_ops(ops, 1, None) == -1
+    assert b"unknown op kind" in _lib.lib.l2d_last_error()
+
+
+def test_weight_packers_cpu():
+    from live2diff_amd import ops
+    w = torch.randn(8, 5, 3, 3)
+    p = ops.pack_conv3x3(w)
+    assert p.shape == (8, 9 * 64) and p.dtype == torch.float16
+    assert torch.equal(p.view(8, 9, 64)[:, 4, :5], w[:, :, 1, 1].half()) and (p.view(8, 9, 64)[:, :, 5:] == 0).all()
+    perm = ops.geglu_perm(64, "cpu")
+    assert perm[:16].tolist() == list(range(16)) and perm[16:32].tolist() == list(range(64, 80)) and perm[32] == 16
+    assert sorted(perm.tolist()) == list(range(128))
+
+
+@pytest.fixture
+def dry_run():
+    from live2diff_amd import _lib, ops
+    _lib.lib.l2d_set_dry_run(1)
+    ops.DRY_RUN = True
+    yield
+    ops.DRY_RUN = False
+    _lib.lib.l2d_set_dry_run(0)
+
+
+@pytest.mark.parametrize("mode", ["stream", "warmup"])
+def test_plan_builds_and_validates_without_gpu(dry_run, mode):
+    """Build the whole UNet plan on CPU tensors and push every op through the C library's argument validation
+    (validate-only mode): catches shape / stride / packing mistakes of the host code without a device."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 256, 256), cross_attention_dim=96)
+    sd = random_state_dict(cfg, dtype=torch.float16)
+    unet = HipStreamingUNet(sd, cfg, 16, 24, 2, device="cpu")
+    kv = unet.prepare_cache(2)
+    assert len(kv) == 40 and kv[0].shape == (2, 2, 16 * 24, 16, 64) and kv[16].shape == (2, 2, 2 * 3, 16, 256)
+    st = unet._plan(mode, kv)
+    st.pl.run(stream=0)                      # validate-only
+    summ = unet.plan_summary(mode)
+    from live2diff_amd import _lib
+    assert summ["kinds"][_lib.OP_TATTN_STREAM if mode == "stream" else _lib.OP_TATTN_WARMUP] == 40
+    assert summ["kinds"][_lib.OP_FLASH_ATTN] == 32 and summ["kinds"][_lib.OP_GN_APPLY] == 22 * 2 + 16 + 20 + 1
+    # a broken op is refused with a message naming it
+    bad = st.pl[5]
+    old = bad.i[15]
+    bad.i[15] = 3                            # ldo not a multiple of 4
+    st.pl._arr = None
+    with pytest.raises(_lib.L2DError):
+        st.pl.run(stream=0)
+    bad.i[15] = old
+
+
+def test_plan_validates_sd15_shapes(dry_run):
+    """SD-1.5 widths at 512x512 / N=2 / L=16 (cfg-2): the whole 1.28 B-parameter plan is built on CPU
+    (zero weights) and every op passes the C library's validation."""
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import unet_param_spec
+    cfg = sd15_config()
+    sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    unet = HipStreamingUNet(sd, cfg, 64, 64, 2, device="cpu")
+    del sd
+    kv = unet.prepare_cache(2)
+    st = unet._plan("stream", kv)
+    st.pl.run(stream=0)
+    assert st.n_ops > 600
+    assert abs(unet.weight_bytes() / 1e9 - 2.6) < 0.2
