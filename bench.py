@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: the per-frame streaming UNet step of Live2Diff on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Unit of work ("step") = one streaming UNet forward over the denoising batch = one output frame
+(reference call site pipeline_stream_animation_depth.py:456-466).  Workload = BASELINE.json configs[1]:
+512x512 image (64x64 latent), 2 denoise steps (t = [399, 199]), window L = 8 sink + 8 rolling = 16,
+SD-1.5 widths (1 277.7 M parameters, random-init key-hashed fp16 weights), synthetic N(0,1) inputs,
+KV caches pre-filled N(0,1), steady-state ring buffer (all 16 slots unmasked: worst case for bandwidth).
+Inputs and weights are resident in HBM before the timed region; every timed step includes the boundary's
+input copies and the host ring-buffer update + upload, exactly as the pipeline drives it.
+
+N GPUs = N independent streams (weak scaling), weights broadcast once over RCCL; `value` = aggregate frames/s.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+
+
+def op_work(op, kinds):
+    """Algorithmic work of one plan op: (flops, bytes) from the record's own fields."""
+    k = op.kind
+    i = op.i
+    if k == kinds.OP_IGEMM:
+        taps, C1, C2, M, Nout, batch = i[0], i[1], i[2], i[13], i[14], max(1, i[20])
+        nreal = Nout
+        flops = 2.0 * M * nreal * taps * (C1 + C2) * batch
+        byts = 2.0 * batch * (M * (C1 + C2) + nreal * taps * (C1 + C2) + M * (Nout // 2 if i[19] == 1 else Nout))
+        return flops, byts
+    if k == kinds.OP_FLASH_ATTN:
+        B, H, d, Tq, Tk = i[0], i[1], i[2], i[3], i[4]
+        return 4.0 * B * H * Tq * Tk * d, 2.0 * B * H * d * (2 * Tq + 2 * Tk)
+    if k in (kinds.OP_TATTN_STREAM,):
+        N, T, C, L = i[0], i[1], i[2], i[3]
+        # K+V slabs read once, new row written, q in / out:  4*N*T*L*C + 8*N*T*C bytes (fp16)
+        return 4.0 * N * T * L * C, 4.0 * N * T * L * C + 8.0 * N * T * C
+    if k in (kinds.OP_GN_STATS,):
+        B, T, C = i[0], i[1], i[2] + i[3]
+        return 3.0 * B * T * C, 2.0 * B * T * C
+    if k in (kinds.OP_GN_APPLY,):
+        B, T, C = i[0], i[1], i[2] + i[3]
+        return 4.0 * B * T * C, 4.0 * B * T * C
+    if k == kinds.OP_LAYERNORM:
+        return 8.0 * i[0] * i[1], 4.0 * i[0] * i[1]
+    return 0.0, 0.0
+
+
+KIND_NAMES = {1: "igemm_kernel", 2: "gn_stats_kernel", 3: "gn_apply_kernel", 4: "layernorm_kernel", 5: "flash_attn_kernel",
+              6: "tattn_stream_kernel", 7: "tattn_warmup_kernel", 8: "skinny_linear_kernel", 9: "timestep_embed_kernel",
+              10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy"}
+
+
+def per_kernel_breakdown(unet, reps=5):
+    """Per-kernel-family time of one frame, measured live with HIP events (l2d_time_ops records hipEvents on the
+    stream the kernels are launched on) by replaying each family's launches of the plan back to back."""
+    from live2diff_amd import _lib
+    st = unet._plans["stream"]
+    groups = {}
+    for j in range(len(st.pl)):
+        groups.setdefault(st.pl[j].kind, []).append(st.pl[j])
+    rows = {}
+    for kind, ops_ in groups.items():
+        pl = _lib.OpList()
+        for op in ops_:
+            c = _lib.L2dOp()
+            import ctypes
+            ctypes.memmove(ctypes.byref(c), ctypes.byref(op), ctypes.sizeof(_lib.L2dOp))
+            pl.append(c)
+        pl.time_ms(1)
+        ms = pl.time_ms(reps)
+        fl = sum(op_work(o, _lib)[0] for o in ops_)
+        by = sum(op_work(o, _lib)[1] for o in ops_)
+        rows[KIND_NAMES.get(kind, str(kind))] = dict(launches=len(ops_), ms=ms, flops=fl, bytes=by,
+                                                     avg_us=1e3 * ms / len(ops_))
+    return rows
+
+
+def cpu_baseline(cfg, sd_cpu16, frames=2):
+    """The oracle (fp32 CPU restatement, `kind: port`) timed on the host cores on a bounded sample of the SAME
+    workload: `frames` timed streaming frames of cfg-2 after one untimed frame."""
+    from oracle import unet_ref as O
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    torch.set_num_threads(os.cpu_count() or 1)
+    h = w = 64
+    N = 2
+    sd32 = {k: v.float() for k, v in sd_cpu16.items()}
+    kv = O.alloc_kv_cache(cfg, h, w, N)
+    g = torch.Generator().manual_seed(0)
+    for c in kv:
+        c.normal_(generator=g)
+    rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)
+    for _ in range(2 * cfg.window_size):
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
+    x = torch.randn(N, 4, 1, h, w, generator=g)
+    d = torch.randn(N, 4, 1, h, w, generator=g)
+    enc = torch.randn(N, 77, cfg.cross_attention_dim, generator=g)
+    ts = torch.tensor([399, 199])
+    times = []
+    for f in range(frames + 1):
+        t0 = time.perf_counter()
+        O.unet_forward(sd32, cfg, x, ts, enc, d, kv, temporal_attention_mask=rb[0], pe_idx=rb[1], update_idx=rb[2])
+        times.append(time.perf_counter() - t0)
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
+    sec = sum(times[1:]) / frames
+    return dict(value=1.0 / sec, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{frames} timed frames (+1 untimed) of the same cfg-2 workload on the fp32 oracle, "
+                       f"{sec:.2f} s/frame, {os.cpu_count()} logical cpus")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--graph", type=int, default=0, help="replay the plan from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--tattn-variant", type=int, default=0)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=2)
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--breakdown", type=int, default=1)
+    args = ap.parse_args()
+
+    from live2diff_amd import _lib, parallel
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict, unet_param_spec
+
+    rank, world, local = parallel.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = sd15_config(window_size=args.window, sink_size=8)
+    N = args.denoise_steps
+    h, w = args.height // 8, args.width // 8
+    default_workload = (args.height, args.width, N, args.window) == (512, 512, 2, 16)
+
+    # ---- weights: generated on rank 0, one-time RCCL broadcast (the only collective of the data path)
+    spec = unet_param_spec(cfg)
+    sd_cpu = random_state_dict(cfg, dtype=torch.float16) if rank == 0 else None
+    sd = parallel.broadcast_state_dict(spec, sd_cpu, dev)
+    unet = HipStreamingUNet(sd, cfg, h, w, N, device=dev, use_graph=bool(args.graph), tattn_variant=args.tattn_variant)
+    del sd
+    kv = unet.prepare_cache(N)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    for c in kv:
+        c.normal_(generator=g)
+    kv_bytes = sum(c.numel() * 2 for c in kv)
+    x = torch.randn(N, 4, 1, h, w, generator=g, device=dev, dtype=torch.float16)
+    d = torch.randn(N, 4, 1, h, w, generator=g, device=dev, dtype=torch.float16)
+    enc = torch.randn(N, 77, cfg.cross_attention_dim, generator=g, device=dev, dtype=torch.float16)
+    ts = torch.tensor([399, 199, 99, 19][:N], device=dev)
+    rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)
+    for _ in range(2 * cfg.window_size):          # steady state: every slot unmasked
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
+
+    def step():
+        bias = rb[0].to(device=dev, dtype=torch.float16, non_blocking=True)
+        pe_idx, upd = rb[1].to(dev, non_blocking=True), rb[2].to(dev, non_blocking=True)
+        out = unet(x, ts, encoder_hidden_states=enc, temporal_attention_mask=bias, depth_sample=d, kv_cache=kv,
+                   pe_idx=pe_idx, update_idx=upd)
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    finite = bool(torch.isfinite(out["sample"]).all())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    result = {
+        "metric": "frames/sec @512x512, 2 denoise steps (streaming UNet step = one output frame)",
+        "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.height}x{args.width} image ({h}x{w} latent), {N} denoise steps, "
+                               f"KV window L={cfg.window_size} (8 sink + {cfg.window_size - 8} rolling), SD-1.5 UNet widths + "
+                               "Live2Diff temporal attention, one independent stream per GPU",
+                   "params_M": 1277.7, "kv_cache_GB_per_stream": round(kv_bytes / 1e9, 3),
+                   "plan_launches": unet.plan_summary()["n_ops"], "hipgraph": bool(args.graph),
+                   "device": unet.device_name, "output_finite": finite, "default_workload": default_workload},
+    }
+    if rank == 0 and args.breakdown:
+        rows = per_kernel_breakdown(unet)
+        tot = sum(r["ms"] for r in rows.values())
+        kernels = {}
+        for name, r in sorted(rows.items(), key=lambda kv_: -kv_[1]["ms"]):
+            ent = {"launches": r["launches"], "ms_per_frame": round(r["ms"], 4), "avg_us": round(r["avg_us"], 2)}
+            if r["flops"] > 0:
+                ent["tflops"] = round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)
+                ent["gbps"] = round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)
+            kernels[name] = ent
+        result["kernels"] = kernels
+        result["kernels_sum_ms"] = round(tot, 4)
+        dom = max(rows.items(), key=lambda kv_: kv_[1]["ms"])
+        name, r = dom
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(name)
+        if name in ("igemm_kernel", "flash_attn_kernel"):
+            ach = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12
+            result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+        else:
+            ach = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9
+            result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic}
+        # the HBM-bound streaming KV-cache kernel is the one north_star singles out: always report it too
+        t = rows.get("tattn_stream_kernel")
+        if t:
+            ach = t["bytes"] / (t["ms"] * 1e-3) / 1e9
+            result["roofline_kv_cache_kernel"] = {"kernel": "tattn_stream_kernel", "bound": "hbm", "achieved": round(ach, 1),
+                                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                                                  "traffic": (json.load(open(tpath)).get("tattn_stream_kernel") if os.path.exists(tpath) else None)}
+        # measured copy bandwidth for context
+        try:
+            import ctypes
+            a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)
+            b = torch.empty_like(a)
+            gb = ctypes.c_float(0)
+            _lib.check(_lib.lib.l2d_copy_bench(a.data_ptr(), b.data_ptr(), a.numel() * 4, 5,
+                                               ctypes.c_void_p(_lib.current_stream_ptr()), ctypes.byref(gb)), "copy_bench")
+            result["hbm_copy_gbps_measured"] = round(float(gb.value), 1)
+            del a, b
+        except Exception as e:  # noqa: BLE001
+            result["hbm_copy_gbps_measured"] = f"error: {e}"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames=args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
