@@ -94,7 +94,7 @@ class _Act:
 class HipStreamingUNet:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig, height: int, width: int,
                  denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
-                 tattn_variant: int = 0):
+                 tattn_variant: int = 0, text_len: int = 77):
         """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names."""
         assert cfg.num_heads == 8 and cfg.temporal_heads == 8
         assert height % 8 == 0 and width % 8 == 0, "latent size must be divisible by 8 (3 down-samplings, T%4==0)"
@@ -103,6 +103,8 @@ class HipStreamingUNet:
         self.F = cfg.sink_size if warmup_frames is None else warmup_frames
         self.use_graph = use_graph
         self.tattn_variant = tattn_variant
+        assert 1 <= text_len <= TEXT_PAD
+        self.text_len = text_len           # static number of text tokens (77 for CLIP)
         self.dtype = torch.float16
         self.config = SimpleNamespace(in_channels=cfg.in_channels)      # read by the reference wrapper (:524)
         self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()   # raises unless a gfx950 is present
@@ -458,7 +460,7 @@ class HipStreamingUNet:
         add(ops.skinny_linear(t_h2, W["temb_all.w"], W["temb_all.b"], st.temb_all, M=Bt, K=E, Nout=self.temb_total))
 
         # ---- text K / V^T for all cross-attention layers (two GEMMs)
-        st.text_len = 77
+        st.text_len = self.text_len
         st.text_k = torch.zeros(Bt * TEXT_PAD, self.text_total, dtype=torch.float16, device=dev)
         st.text_vt = torch.zeros(Bt, self.text_total, TEXT_PAD, dtype=torch.float16, device=dev)
         D = cfg.cross_attention_dim
@@ -574,8 +576,6 @@ class HipStreamingUNet:
             raise ValueError(f"sample shape {tuple(sample.shape)} != static {(N, cfg.in_channels, 1, self.h, self.w)}")
         if kv_cache is None or len(kv_cache) != len(self.mm_layout):
             raise ValueError(f"kv_cache must be the list of {len(self.mm_layout)} caches from prepare_cache()")
-        if encoder_hidden_states.shape[1] != 77 and encoder_hidden_states.shape[1] > TEXT_PAD:
-            raise ValueError("encoder_hidden_states: at most 80 tokens supported")
         st = self._plan("stream", kv_cache)
         self._bind_caches(st, kv_cache)
         st.text_len_rt = encoder_hidden_states.shape[1]

@@ -222,7 +222,7 @@ def gen_unet_rollout():
     P = ref_loader.load_pipeline_class()
     cls = P.StreamAnimateDiffusionDepth
     torch.Tensor.cuda = lambda self, *a, **k: self
-    cfg = tiny_config(channels=(32, 64, 64, 64), cross_attention_dim=64)
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
     spec = unet_param_spec(cfg)
     sd = {k: _fill(k, shp, 1.0) for k, shp in spec.items()}
     us = R.unet_depth_streaming.UNet3DConditionStreamingModel(**unet_kwargs(cfg, True))

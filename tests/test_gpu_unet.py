@@ -110,3 +110,35 @@ def test_sd15_width_single_step(golden):
     report, unet = _rollout(cfg, 32, 32, 2, 2, golden)
     print(unet.plan_summary())
     _assert(report)
+
+
+def test_rollout_against_reference_golden(golden):
+    """HIP backend directly against outputs captured from the REFERENCE's own UNet classes (fp32, key-hashed
+    weights; tests/golden/unet_rollout.npz): 2 warm-up passes + 12 streaming frames with the reference's
+    ring-buffer trace.  Tolerance: rel-L2 <= 1e-2, cosine >= 0.9995 (fp16 weights + fp16 kernels vs fp32 reference)."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    g, sm = golden("unet_rollout"), golden("state_machine")
+    h, w, N, FR = [int(v) for v in g["meta"]]
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    sd = random_state_dict(cfg, dtype=torch.float16, device=DEV)
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    enc = T(g["enc"])
+    unet = HipStreamingUNet(sd, cfg, h, w, N, text_len=enc.shape[1])
+    kv = unet.prepare_cache(N)
+    ts = T(g["tsteps"])
+    rep = []
+    for idx in range(N):
+        out = unet.warmup(T(g["warm_x"])[idx:idx + 1].half().to(DEV), ts[idx:idx + 1].to(DEV),
+                          encoder_hidden_states=enc.half().to(DEV), depth_sample=T(g["warm_depth"]).half().to(DEV),
+                          kv_cache=kv, row=idx)["sample"]
+        rep.append(("warmup", idx, rel(out, T(g["warm_out"])[idx]), cos(out, T(g["warm_out"])[idx])))
+    for f in range(FR):
+        out = unet(T(g["xs"])[f].half().to(DEV), ts.to(DEV), encoder_hidden_states=enc.repeat(N, 1, 1).half().to(DEV),
+                   temporal_attention_mask=T(sm["bias_n2"])[f].half().to(DEV), depth_sample=T(g["ds"])[f].half().to(DEV),
+                   kv_cache=kv, pe_idx=T(sm["pe_idx_n2"])[f].to(DEV), update_idx=T(sm["update_idx_n2"])[f].to(DEV))["sample"]
+        rep.append(("stream", f, rel(out, T(g["outs"])[f]), cos(out, T(g["outs"])[f])))
+    sl = torch.stack([c[:, :, :1, :, :8] for c in kv]).float().cpu()
+    rep.append(("cache-slice", 0, rel(sl, T(g["cache_slice"])), 1.0))
+    _assert(rep)

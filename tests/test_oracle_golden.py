@@ -38,7 +38,7 @@ def test_pe_table(golden):
 def test_param_spec_matches_reference():
     with open(os.path.join(GOLDEN, "param_spec_tiny.json")) as f:
         ref = json.load(f)
-    spec = unet_param_spec(tiny_config(channels=(32, 64, 64, 64), cross_attention_dim=64))
+    spec = unet_param_spec(tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64))
     assert set(ref) == set(spec)
     for k, shp in spec.items():
         assert list(shp) == ref[k], k
@@ -161,7 +161,7 @@ def test_unet_rollout(golden):
     g = golden("unet_rollout")
     sm = golden("state_machine")
     h, w, N, FR = [int(v) for v in g["meta"]]
-    cfg = tiny_config(channels=(32, 64, 64, 64), cross_attention_dim=64)
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
     sd = {k: _fill(k, shp, 1.0) for k, shp in unet_param_spec(cfg).items()}
     kv = O.alloc_kv_cache(cfg, h, w, N)
     enc, ts = T(g["enc"]), T(g["tsteps"])
