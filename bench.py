@@ -89,6 +89,39 @@ def per_kernel_breakdown(unet, reps=5):
     return rows
 
 
+def per_op_table(unet, path, reps=10):
+    """Every launch of the frame timed on its own (HIP events, `reps` back-to-back runs): CSV for tuning."""
+    import ctypes
+
+    from live2diff_amd import _lib
+    st = unet._plans["stream"]
+    with open(path, "w") as f:
+        f.write("tag,kernel,dims,us,tflops,gbps\n")
+        for j in range(len(st.pl)):
+            op = st.pl[j]
+            c = _lib.L2dOp()
+            ctypes.memmove(ctypes.byref(c), ctypes.byref(op), ctypes.sizeof(_lib.L2dOp))
+            pl = _lib.OpList()
+            pl.append(c)
+            pl.time_ms(2)
+            us = 1e3 * pl.time_ms(reps)
+            fl, by = op_work(op, _lib)
+            i = op.i
+            if op.kind == _lib.OP_IGEMM:
+                dims = f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} s{i[11]} u{i[12]} e{i[19]} b{max(1, i[20])}"
+            elif op.kind == _lib.OP_FLASH_ATTN:
+                dims = f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
+            elif op.kind in (_lib.OP_TATTN_STREAM, _lib.OP_TATTN_WARMUP):
+                dims = f"N{i[0]} T{i[1]} C{i[2]} L{i[3]}"
+            elif op.kind in (_lib.OP_GN_STATS, _lib.OP_GN_APPLY):
+                dims = f"B{i[0]} T{i[1]} C{i[2] + i[3]} nchunk{i[7]}"
+            elif op.kind == _lib.OP_LAYERNORM:
+                dims = f"rows{i[0]} C{i[1]}"
+            else:
+                dims = ""
+            f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{dims},{us:.2f},{fl / us / 1e6 if us else 0:.2f},{by / us / 1e3 if us else 0:.1f}\n")
+
+
 def cpu_baseline(cfg, sd_cpu16, frames=2):
     """The oracle (fp32 CPU restatement, `kind: port`) timed on the host cores on a bounded sample of the SAME
     workload: `frames` timed streaming frames of cfg-2 after one untimed frame."""
@@ -135,13 +168,14 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=2)
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--breakdown", type=int, default=1)
+    ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
     args = ap.parse_args()
 
     from live2diff_amd import _lib, parallel
     from live2diff_amd.config import sd15_config
     from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
     from live2diff_amd.unet_hip import HipStreamingUNet
-    from live2diff_amd.weights import random_state_dict, unet_param_spec
+    from live2diff_amd.weights import device_random_state_dict, random_state_dict, unet_param_spec
 
     rank, world, local = parallel.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -154,7 +188,11 @@ def main():
 
     # ---- weights: generated on rank 0, one-time RCCL broadcast (the only collective of the data path)
     spec = unet_param_spec(cfg)
-    sd_cpu = random_state_dict(cfg, dtype=torch.float16) if rank == 0 else None
+    need_cpu_weights = (world == 1 and not args.no_cpu_baseline)     # the CPU baseline runs the oracle on the same weights
+    if rank == 0:
+        sd_cpu = random_state_dict(cfg, dtype=torch.float16) if need_cpu_weights else device_random_state_dict(cfg, dev)
+    else:
+        sd_cpu = None
     sd = parallel.broadcast_state_dict(spec, sd_cpu, dev)
     unet = HipStreamingUNet(sd, cfg, h, w, N, device=dev, use_graph=bool(args.graph), tattn_variant=args.tattn_variant)
     del sd
@@ -252,6 +290,8 @@ def main():
             del a, b
         except Exception as e:  # noqa: BLE001
             result["hbm_copy_gbps_measured"] = f"error: {e}"
+    if rank == 0 and args.per_op:
+        per_op_table(unet, args.per_op)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames=args.cpu_frames)
     if rank == 0:

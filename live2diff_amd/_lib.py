@@ -7,6 +7,9 @@ module raises, and every op raises `L2DError` when the library reports a failure
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede loading libl2d_hip.so: the extension has to bind to the HIP runtime torch
+#                      already loaded (one runtime per process: shared streams and device pointers)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libl2d_hip.so")
 

@@ -70,13 +70,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_block) {
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ float s_part[4][64][2];
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
     const int b = blockIdx.y;
-    if (tid < a.G) {
+    {   // deterministic reduction of the per-chunk partials: 4 slices x G groups in parallel, fixed order
+        const int g = tid & 63, part = tid >> 6;
         float s = 0.f, q = 0.f;
-        const float *src = a.partial + ((long long)b * a.nchunk * a.G + tid) * 2;
-        for (int ch = 0; ch < a.nchunk; ++ch) { s += src[0]; q += src[1]; src += a.G * 2; }
+        if (g < a.G) {
+            for (int ch = part; ch < a.nchunk; ch += 4) {
+                const float *src = a.partial + (((long long)b * a.nchunk + ch) * a.G + g) * 2;
+                s += src[0]; q += src[1];
+            }
+        }
+        s_part[part][g][0] = s; s_part[part][g][1] = q;
+    }
+    __syncthreads();
+    if (tid < a.G) {
+        float s = (s_part[0][tid][0] + s_part[1][tid][0]) + (s_part[2][tid][0] + s_part[3][tid][0]);
+        float q = (s_part[0][tid][1] + s_part[1][tid][1]) + (s_part[2][tid][1] + s_part[3][tid][1]);
         float inv = 1.0f / ((float)a.T * (float)cpg);
         float mean = s * inv;
         float var = fmaxf(q * inv - mean * mean, 0.f);
@@ -143,8 +155,8 @@ int l2d_launch_gn_apply(const l2d_op *op, hipStream_t s) {
     if (rc) return rc;
     L2D_DRY_RETURN();
     int C = a.C1 + a.C2;
-    // ~64 KB of activations per block, at least one pass of pixel rows
-    int ppb = (32768 + C - 1) / C;
+    // ~16 KB of activations per block (enough blocks to fill 256 CUs at the large levels), at least one pass of pixel rows
+    int ppb = (8192 + C - 1) / C;
     int pr = 256 / ((C / 8) < 256 ? (C / 8) : 256);
     if (ppb < pr) ppb = pr;
     if (ppb > a.T) ppb = a.T;

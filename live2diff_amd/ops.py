@@ -66,13 +66,47 @@ def f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # ----------------------------------------------------------------------------- op builders
+_ZERO_PAGES = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    """256 bytes of zeros per device: the DMA source for conv padding / ragged rows / channel tails (igemm.hip)."""
+    key = str(device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros(128, dtype=torch.float16, device=device)
+    return _ZERO_PAGES[key]
+
+
+def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
+    """(tile, splitk) for an implicit GEMM.  tile 1 = 128x128, 2 = 64x64.  Goal: >= ~1 wave of blocks over the 256
+    CUs; the low-resolution levels (M = 128..2048 tokens, K up to 23 040) get there by splitting K (>= 16
+    pipeline stages = 512 K-elements per split) instead of shrinking the tile."""
+    cdiv = lambda a, b: (a + b - 1) // b
+    nk = Kp // 32
+    big = cdiv(Nout, 128) * cdiv(M, 128) * batch
+    if big >= 192:
+        return 1, 1
+    can_split = epi != 1
+    if can_split:
+        s_big = max(1, min(nk // 16, round(256 / big), 64))
+        if s_big >= 2 and big * s_big >= 128:
+            return 1, s_big
+    small = cdiv(Nout, 64) * cdiv(M, 64) * batch
+    s_small = max(1, min(nk // 16, round(512 / small), 64)) if can_split else 1
+    if small >= 384:
+        s_small = 1
+    return 2, s_small
+
+
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
-          batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0):
-    """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors."""
+          batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None):
+    """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
+    splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
     op.kind = _lib.OP_IGEMM
     es = 2
+    zp = zero_page(x1.device)
     op.p[0] = _ptr(_h(x1)) + x1_off * es
     op.p[1] = _ptr(x2) if x2 is not None else None
     op.p[2] = _ptr(_h(w)) + w_off * es
@@ -80,16 +114,20 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     op.p[4] = _ptr(rowbias)
     op.p[5] = (_ptr(res) + res_off * es) if res is not None else None
     op.p[6] = _ptr(_h(out)) + out_off * es
+    op.p[7] = _ptr(zp)
+    op.p[8] = _ptr(ws)
     if bias is not None:
         assert bias.dtype == torch.float32
     if rowbias is not None:
         assert rowbias.dtype == torch.float32
+    if splitk > 1:
+        assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
-            rows_per_bias, epi, batch]
+            rows_per_bias, epi, batch, splitk, tile]
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
-    return op, (x1, x2, w, bias, rowbias, res, out)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):

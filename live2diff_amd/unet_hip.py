@@ -103,6 +103,7 @@ class HipStreamingUNet:
         self.F = cfg.sink_size if warmup_frames is None else warmup_frames
         self.use_graph = use_graph
         self.tattn_variant = tattn_variant
+        self.igemm_splitk_off = False       # tuning knob: disable split-K schedules
         assert 1 <= text_len <= TEXT_PAD
         self.text_len = text_len           # static number of text tokens (77 for CLIP)
         self.dtype = torch.float16
@@ -266,6 +267,18 @@ class HipStreamingUNet:
             pl.append(op, *keep)
             return op
 
+        def gemm(x1, wt, out, **kw):
+            """igemm with the (tile, split-K) schedule chosen for its shape; the fp32 split-K workspace comes from
+            the arena and is released right after (stream order makes the reuse safe)."""
+            batch, taps = kw.get("batch", 1), kw.get("taps", 1)
+            tile, S = ops.igemm_schedule(kw["M"], kw["Nout"], taps * kw["CinP"], batch, kw.get("epi", 0))
+            if self.igemm_splitk_off:
+                S = 1
+            ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, **kw))
+            ar.release(ws)
+            return op
+
         # ---- static inputs
         st.in_sample = torch.zeros(B, cfg.in_channels, h * w, dtype=torch.float16, device=dev)
         st.in_depth = torch.zeros_like(st.in_sample)
@@ -288,7 +301,7 @@ class HipStreamingUNet:
         def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
             T = x.H * x.W
             C2 = x2.C if x2 is not None else 0
-            nchunk = max(1, min(32, T // 64))
+            nchunk = max(1, min(128, T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
             out = new_act(x.C + C2, x.H, x.W)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
@@ -314,19 +327,18 @@ class HipStreamingUNet:
             if rowbias is not None:
                 off = rowbias
                 kw = dict(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(Ho * Wo if mode == "stream" else B * Ho * Wo))
-            opk = ops.igemm(x.buf, wt, out.buf, M=B * Ho * Wo, Nout=cout, C1=x.C, ldx1=x.C, CinP=cinp, ldo=cout,
+            op_ = gemm(x.buf, wt, out.buf, M=B * Ho * Wo, Nout=cout, C1=x.C, ldx1=x.C, CinP=cinp, ldo=cout,
                             bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
                             taps=9, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, stride=stride, ups=ups, epi=epi, **kw)
             if rowbias is not None:
-                opk[0].p[4] = st.temb_all.data_ptr() + 4 * rowbias
-            add(opk)
+                op_.p[4] = st.temb_all.data_ptr() + 4 * rowbias
             return out
 
         def linear_raw(xbuf, M, K, ldx, wt, outbuf, ldo, bias=None, res=None, ldr=0, epi=0, x2=None, C2=0, ldx2=0,
                        **kw):
             nout = wt.shape[0]
-            add(ops.igemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
-                          res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw))
+            gemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
+                          res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw)
 
         def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None) -> _Act:
             wt = W[wkey or (name + ".w")]
@@ -382,8 +394,8 @@ class HipStreamingUNet:
             vt = ar.alloc(B * C * ldvt)
             # V^T[b] = Wv . n1[b]^T : the same GEMM with operand roles swapped (tokens act as "channels")
             wv = W[b + ".attn1.v"]
-            add(ops.igemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
-                          sw=T * C, so=C * ldvt))
+            gemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
+                          sw=T * C, so=C * ldvt)
             free(n1)
             ao = new_act(C, x.H, x.W)
             add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
@@ -464,11 +476,11 @@ class HipStreamingUNet:
         st.text_k = torch.zeros(Bt * TEXT_PAD, self.text_total, dtype=torch.float16, device=dev)
         st.text_vt = torch.zeros(Bt, self.text_total, TEXT_PAD, dtype=torch.float16, device=dev)
         D = cfg.cross_attention_dim
-        add(ops.igemm(st.in_enc, W["text_k.w"], st.text_k, M=Bt * TEXT_PAD, Nout=self.text_total, C1=D, ldx1=self.text_kp,
-                      CinP=self.text_kp, ldo=self.text_total))
-        add(ops.igemm(W["text_v.w"], st.in_enc, st.text_vt, M=self.text_total, Nout=TEXT_PAD, C1=D, ldx1=self.text_kp,
+        gemm(st.in_enc, W["text_k.w"], st.text_k, M=Bt * TEXT_PAD, Nout=self.text_total, C1=D, ldx1=self.text_kp,
+                      CinP=self.text_kp, ldo=self.text_total)
+        gemm(W["text_v.w"], st.in_enc, st.text_vt, M=self.text_total, Nout=TEXT_PAD, C1=D, ldx1=self.text_kp,
                       CinP=self.text_kp, ldo=TEXT_PAD, batch=Bt, sx1=0, sw=TEXT_PAD * self.text_kp,
-                      so=self.text_total * TEXT_PAD))
+                      so=self.text_total * TEXT_PAD)
 
         # ---- input: NCHW latents -> channels-last (padded to 8 channels), conv_in + depth mapping network
         x_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)

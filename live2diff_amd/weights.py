@@ -173,6 +173,29 @@ def random_state_dict(cfg: UNetConfig, dtype=torch.float32, device="cpu", gain: 
     return OrderedDict((k, _fill(k, shp, gain).to(device=device, dtype=dtype)) for k, shp in unet_param_spec(cfg).items())
 
 
+def device_random_state_dict(cfg: UNetConfig, device, dtype=torch.float16, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Same distribution as `random_state_dict`, generated directly on the device (seed = crc32(key) on the device
+    generator): for benchmarks that do not need bit-identical CPU weights (seconds instead of ~1 min for 1.28 B)."""
+    out = OrderedDict()
+    g = torch.Generator(device=device)
+    for k, shp in unet_param_spec(cfg).items():
+        g.manual_seed(zlib.crc32(k.encode()) & 0x7FFFFFFF)
+        x = torch.randn(shp, generator=g, dtype=torch.float32, device=device)
+        leaf = k.rsplit(".", 1)[-1]
+        is_norm = any(s in k for s in (".norm", "norms.", "ff_norm", "conv_norm_out"))
+        if leaf == "bias":
+            x = 0.05 * x
+        elif is_norm:
+            x = 1.0 + 0.1 * x
+        else:
+            fan_in = 1
+            for s_ in shp[1:]:
+                fan_in *= s_
+            x = x * (gain * fan_in ** -0.5)
+        out[k] = x.to(dtype)
+    return out
+
+
 def count_params(cfg: UNetConfig) -> int:
     n = 0
     for shp in unet_param_spec(cfg).values():

@@ -106,6 +106,48 @@ def test_igemm_swapped_batched(L):
     check(out[:, :, :T], ref, what="swapped batched")
 
 
+@pytest.mark.parametrize("M,K,N,S,tile", [(128, 2560, 1280, 8, 1), (512, 1280, 320, 4, 2), (2048, 640, 640, 2, 1),
+                                          (300, 1024, 70, 5, 2), (128, 11520, 256, 24, 1)])
+def test_igemm_splitk(L, M, K, N, S, tile):
+    x = rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3).float()
+    r = rnd(M, N + 2, seed=4)
+    ref = F.silu(x.float() @ w.float().t() + b) + r.float()[:, :N]
+    wp = L.pack_linear(w.to(DEV))
+    ldo = (N + 3) // 4 * 4
+    out = torch.zeros(M, ldo, dtype=torch.float16, device=DEV)
+    ws = torch.full((S * M * ldo,), float("nan"), dtype=torch.float32, device=DEV)
+    ldr = (N + 2 + 3) // 4 * 4
+    rp = torch.zeros(M, ldr, dtype=torch.float16)
+    rp[:, :N + 2] = r
+    L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, CinP=wp.shape[1], ldo=ldo, bias=b.to(DEV), res=rp.to(DEV),
+                  ldr=ldr, epi=2, splitk=S, tile=tile, ws=ws))
+    torch.cuda.synchronize()
+    check(out[:, :N], ref, what=f"splitk {M}x{K}x{N} S{S}")
+
+
+def test_igemm_schedule_matches_plain(L):
+    """the (tile, split-K) schedule picked for the UNet's conv shapes gives the same result as tile=2, S=1"""
+    from live2diff_amd.ops import igemm_schedule
+    B, cin, cout, H, W = 2, 320, 128, 8, 8
+    x = rnd(B, H, W, cin, seed=1).to(DEV)
+    wp = L.pack_conv3x3(rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5).to(DEV))
+    M = B * H * W
+    tile, S = igemm_schedule(M, cout, wp.shape[1], 1, 0)
+    assert S > 1
+    outs = []
+    for (t_, s_) in ((2, 1), (tile, S), (1, 3)):
+        out = torch.empty(M, cout, dtype=torch.float16, device=DEV)
+        ws = torch.empty(s_ * M * cout, dtype=torch.float32, device=DEV) if s_ > 1 else None
+        L.run(L.igemm(x, wp, out, M=M, Nout=cout, C1=cin, ldx1=cin, CinP=wp.shape[1] // 9, ldo=cout, taps=9, B=B, Hin=H, Win=W,
+                      Hout=H, Wout=W, splitk=s_, tile=t_, ws=ws))
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+    check(outs[1], outs[0], tol=1e-3, what="schedule vs plain")
+    check(outs[2], outs[0], tol=1e-3, what="big split vs plain")
+
+
 # ----------------------------------------------------------------------------- igemm: conv
 @pytest.mark.parametrize("cin,cout,H,W,stride,ups", [(64, 64, 8, 8, 1, 0), (8, 64, 12, 10, 1, 0), (96, 64, 9, 7, 1, 0),
                                                      (64, 128, 12, 10, 2, 0), (64, 64, 5, 6, 1, 1), (320, 320, 32, 32, 1, 0),
@@ -166,7 +208,7 @@ def test_groupnorm(L, C1, C2, T, silu):
     ref = F.group_norm(xc.float().permute(0, 2, 1), G, gm.float(), bt.float(), eps).permute(0, 2, 1)
     if silu:
         ref = F.silu(ref)
-    nchunk = max(1, min(32, T // 64))
+    nchunk = max(1, min(128, T // 16))
     partial = torch.empty(B * nchunk * G * 2, dtype=torch.float32, device=DEV)
     out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
     kw = dict(B=B, T=T, C1=C1, ld1=C1, G=G, nchunk=nchunk, x2=(x2.to(DEV) if C2 else None), C2=C2, ld2=C2)
