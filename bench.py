@@ -89,6 +89,31 @@ def per_kernel_breakdown(unet, reps=5):
     return rows
 
 
+def tattn_variant_sweep(unet, reps=5):
+    """A/B of the streaming temporal-attention kernel variants on this frame's 40 launches (same process,
+    interleaved): ms per frame for variant 1 (register resident), 2 (chunked CH=8), 3 (chunked CH=4)."""
+    import ctypes
+
+    from live2diff_amd import _lib
+    st = unet._plans["stream"]
+    src = [st.pl[j] for j in range(len(st.pl)) if st.pl[j].kind == _lib.OP_TATTN_STREAM]
+    lists = {}
+    for v in (1, 2, 3):
+        pl = _lib.OpList()
+        for op in src:
+            c = _lib.L2dOp()
+            ctypes.memmove(ctypes.byref(c), ctypes.byref(op), ctypes.sizeof(_lib.L2dOp))
+            c.i[5] = v
+            pl.append(c)
+        lists[v] = pl
+    out = {v: [] for v in lists}
+    for _ in range(3):
+        for v, pl in lists.items():
+            pl.time_ms(1)
+            out[v].append(pl.time_ms(reps))
+    return {f"v{v}": round(min(t), 4) for v, t in out.items()}
+
+
 def per_op_table(unet, path, reps=10):
     """Every launch of the frame timed on its own (HIP events, `reps` back-to-back runs): CSV for tuning."""
     import ctypes
@@ -257,6 +282,8 @@ def main():
             kernels[name] = ent
         result["kernels"] = kernels
         result["kernels_sum_ms"] = round(tot, 4)
+        if args.window <= 16:
+            result["tattn_variants_ms_per_frame"] = tattn_variant_sweep(unet)
         dom = max(rows.items(), key=lambda kv_: kv_[1]["ms"])
         name, r = dom
         traffic = None

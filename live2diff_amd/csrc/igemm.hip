@@ -27,8 +27,6 @@
 //   * XCD-aware block order: consecutive tiles (same token tile, neighbouring weight tiles) land on one XCD.
 #include "common.h"
 
-#define BKS 32      // K elements per pipeline stage
-#define NSTAGE 4
 
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -79,21 +77,25 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
     *reinterpret_cast<h16x4 *>(outp + (long long)m * a.ldo + n) = o;
 }
 
-template <int TN, int TM, int TAPS>
+template <int TN, int TM, int TAPS, int BK, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
-    constexpr int NI = TN / 32;   // 16-row fragments per wave along channels
-    constexpr int MI = TM / 32;   // 16-col fragments per wave along tokens
-    constexpr int NIW = TN / 64;  // DMA instructions per wave per stage (weights): 16 rows x 64 B each
-    constexpr int NIX = TM / 64;  // ... (tokens)
+    constexpr int NI = TN / 32;        // 16-row fragments per wave along channels
+    constexpr int MI = TM / 32;        // 16-col fragments per wave along tokens
+    constexpr int SPR = BK / 8;        // 16-byte slots per LDS row (4 or 8)
+    constexpr int RPI = 64 / SPR;      // rows covered by one DMA wave-instruction (16 or 8)
+    constexpr int NIW = TN / RPI / 4;  // DMA instructions per wave per stage (weights)
+    constexpr int NIX = TM / RPI / 4;  // ... (tokens)
     constexpr int LPS = NIW + NIX;
-    constexpr int STAGE = (TN + TM) * BKS;   // halfs
-    __shared__ __attribute__((aligned(16))) h16 smem[NSTAGE * STAGE];
+    constexpr int KK = BK / 32;        // MFMA K sub-steps per stage
+    constexpr int STAGE = (TN + TM) * BK;   // halfs
+    extern __shared__ __attribute__((aligned(16))) h16 smem[];   // NS * STAGE halfs (the ONLY LDS object)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
+    auto swz = [](int r) { return BK == 32 ? ((r >> 1) & 3) : (r & 7); };
 
     // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs): bijective remap so that
     // consecutive tiles -- same token tile, neighbouring weight tiles -- share one XCD's L2
@@ -114,14 +116,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     const h16 *resp = a.res ? a.res + z * a.sres : nullptr;
     const int Ctot = a.C1 + a.C2;
 
-    // ---- per-lane DMA descriptors.  Within a 16-row group lane l serves row (l>>2), physical slot (l&3).
-    const int lrow = lane >> 2, pslot = lane & 3;
+    // ---- per-lane DMA descriptors.  Within an RPI-row group lane l serves row l/SPR, physical slot l%SPR.
+    const int lrow = lane / SPR, pslot = lane % SPR;
     const h16 *wsrc[NIW];
     int wstep[NIW];
 #pragma unroll
     for (int j = 0; j < NIW; ++j) {
-        const int r = (j * 4 + wave) * 16 + lrow;
-        const int ls = pslot ^ ((r >> 1) & 3);
+        const int r = (j * 4 + wave) * RPI + lrow;
+        const int ls = pslot ^ swz(r);
         const int n = n0 + r;
         const bool ok = n < a.Nout;
         wsrc[j] = ok ? wp + (long long)n * a.Kp + ls * 8 : a.zero;
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     bool xv[NIX];
 #pragma unroll
     for (int j = 0; j < NIX; ++j) {
-        const int r = (j * 4 + wave) * 16 + lrow;
-        xls[j] = (pslot ^ ((r >> 1) & 3)) * 8;
+        const int r = (j * 4 + wave) * RPI + lrow;
+        xls[j] = (pslot ^ swz(r)) * 8;
         const int m = m0 + r;
         xv[j] = m < a.M;
         if (TAPS == 9) {
@@ -146,26 +148,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         }
     }
 
-    auto issue = [&](int kt) {
-        h16 *st = smem + (kt & (NSTAGE - 1)) * STAGE;
-        const int k0 = kt * BKS;
+    // split-K: this block owns K steps [kb, ke)
+    const int nk = a.Kp / BK;
+    const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
+    const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
+
+    // issue() is called for consecutive stages kb, kb+1, ...: ring slot, k offset and the conv tap are tracked
+    // incrementally (no division / modulo in the loop)
+    int is_slot = 0, is_k0 = kb * BK, is_tap = 0, is_cb = kb * BK;
+    if (TAPS == 9) {
+        is_tap = is_k0 / a.CinP;
+        is_cb = is_k0 - is_tap * a.CinP;
+    }
+    auto issue = [&]() {
+        h16 *st = smem + is_slot * STAGE;
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
             const int grp = j * 4 + wave;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(wsrc[j] + (long long)wstep[j] * k0), L2D_LPTR(st + grp * 16 * BKS), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(wsrc[j] + (long long)wstep[j] * is_k0), L2D_LPTR(st + grp * RPI * BK), 16, 0, 0);
         }
-        int cb, ky = 0, kx = 0;
+        int ky = 0, kx = 0;
         if (TAPS == 9) {
-            const int tap = k0 / a.CinP;
-            cb = k0 - tap * a.CinP;
-            ky = tap / 3; kx = tap - ky * 3;
-        } else {
-            cb = k0;
+            ky = (is_tap * 11) >> 5;          // tap / 3 for tap in [0, 9)
+            kx = is_tap - ky * 3;
         }
 #pragma unroll
         for (int j = 0; j < NIX; ++j) {
             const int grp = j * 4 + wave;
-            const int c = cb + xls[j];
+            const int c = is_cb + xls[j];
             bool ok = xv[j] && c < Ctot;
             long long pix;
             if (TAPS == 9) {
@@ -178,8 +188,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
             }
             const h16 *src = a.zero;
             if (ok) src = (c < a.C1) ? x1 + pix * a.ldx1 + c : a.x2 + pix * a.ldx2 + (c - a.C1);
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * 16) * BKS), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * RPI) * BK), 16, 0, 0);
         }
+        is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
+        is_k0 += BK;
+        is_cb += BK;
+        if (TAPS == 9 && is_cb >= a.CinP) { is_cb -= a.CinP; ++is_tap; }
     };
 
     f32x4 acc[NI][MI];
@@ -188,48 +202,48 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // split-K: this block owns K steps [kb, ke)
-    const int nk = a.Kp / BKS;
-    const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
-    const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
-
-    auto compute = [&](int kt) {
-        const h16 *st = smem + (kt & (NSTAGE - 1)) * STAGE;
-        h16x8 af[NI], bf[MI];
+    int cp_slot = 0;
+    auto compute = [&]() {
+        const h16 *st = smem + cp_slot * STAGE;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int r = wn * (TN / 2) + i * 16 + li;
-            af[i] = l2d_ld8(st + r * BKS + ((lg ^ ((r >> 1) & 3)) << 3));
+        for (int kk = 0; kk < KK; ++kk) {
+            h16x8 af[NI], bf[MI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = wn * (TN / 2) + i * 16 + li;
+                af[i] = l2d_ld8(st + r * BK + (((kk * 4 + lg) ^ swz(r)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int r = wm * (TM / 2) + j * 16 + li;
+                bf[j] = l2d_ld8(st + (TN + r) * BK + (((kk * 4 + lg) ^ swz(r)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const int r = wm * (TM / 2) + j * 16 + li;
-            bf[j] = l2d_ld8(st + (TN + r) * BKS + ((lg ^ ((r >> 1) & 3)) << 3));
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
     };
 
-    // prologue: NSTAGE-1 stages in flight
+    // prologue: NS-1 stages in flight
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (kb + s < ke) issue(kb + s);
-    // steady state: stage kt has landed when at most (NSTAGE-2) younger stages are still outstanding
+    for (int s = 0; s < NS - 1; ++s)
+        if (kb + s < ke) issue();
+    // steady state: stage kt has landed when at most (NS-2) younger stages are still outstanding
     int kt = kb;
-    for (; kt + (NSTAGE - 1) < ke; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPS) : "memory");
+    for (; kt + (NS - 1) < ke; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();      // every wave's share of stage kt is in LDS; everyone finished stage kt-1
-        issue(kt + NSTAGE - 1);            // refill the ring slot that stage kt-1 occupied
-        compute(kt);
+        issue();                           // refill the ring slot that stage kt-1 occupied
+        compute();
     }
-    // drain: no more refills; wait for everything, then the remaining (<= NSTAGE-1) stages
+    // drain: no more refills; wait for everything, then the remaining (<= NS-1) stages
     for (; kt < ke; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        compute(kt);
+        compute();
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -303,14 +317,36 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
     igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
 }
 
-template <int TN, int TM>
-static void launch_t(const IGemmArgs &a, int batch, hipStream_t s) {
+template <int TN, int TM, int TAPS, int BK, int NS>
+static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
+    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
+    static bool attr_done = false;
+    if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, TAPS, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_done = true;
+    }
     int ntn = (a.Nout + TN - 1) / TN, ntm = (a.M + TM - 1) / TM;
     dim3 grid(ntn * ntm, a.splitk, batch), block(256);
-    if (a.taps == 9)
-        hipLaunchKernelGGL((igemm_kernel<TN, TM, 9>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((igemm_kernel<TN, TM, 1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((igemm_kernel<TN, TM, TAPS, BK, NS>), grid, block, LDS, s, a);
+}
+
+// pipeline variants (op.i[23]): 0 = BK32 x 4 stages (default), 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3, 5 = BK64 x 2
+template <int TN, int TM, int TAPS>
+static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
+    switch (variant) {
+        case 0: launch_v<TN, TM, TAPS, 32, 4>(a, batch, s); return L2D_OK;
+        case 1: launch_v<TN, TM, TAPS, 64, 3>(a, batch, s); return L2D_OK;
+        case 2: launch_v<TN, TM, TAPS, 64, 4>(a, batch, s); return L2D_OK;
+        case 3: launch_v<TN, TM, TAPS, 32, 6>(a, batch, s); return L2D_OK;
+        case 4: launch_v<TN, TM, TAPS, 32, 3>(a, batch, s); return L2D_OK;
+        case 5: launch_v<TN, TM, TAPS, 64, 2>(a, batch, s); return L2D_OK;
+    }
+    return L2D_EINVAL;
+}
+
+template <int TN, int TM>
+static int launch_t(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
+    return a.taps == 9 ? launch_p<TN, TM, 9>(a, batch, variant, s) : launch_p<TN, TM, 1>(a, batch, variant, s);
 }
 
 int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
@@ -325,6 +361,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     int batch = op->i[20] > 0 ? op->i[20] : 1;
     a.splitk = op->i[21] > 0 ? op->i[21] : 1;
     int tile = op->i[22];   // 0 auto, 1 = 128x128, 2 = 64x64
+    int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.Kp = a.taps * a.CinP;
     if (!a.x1 || !a.w || !a.out || !a.zero || (a.taps != 1 && a.taps != 9) || a.CinP <= 0 || a.CinP % 64 != 0 ||
@@ -332,7 +369,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1)) || (a.stride != 1 && a.stride != 2) ||
-        (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / BKS ||
+        (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 || variant < 0 || variant > 5 ||
         a.splitk > 64) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
@@ -348,8 +385,8 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         long long big = (long long)((a.Nout + 127) / 128) * ((a.M + 127) / 128) * batch * a.splitk;
         tile = (big >= 192) ? 1 : 2;
     }
-    if (tile == 1) launch_t<128, 128>(a, batch, s);
-    else launch_t<64, 64>(a, batch, s);
+    if (tile == 1) launch_t<128, 128>(a, batch, variant, s);
+    else launch_t<64, 64>(a, batch, variant, s);
     int rc = l2d_check_launch("igemm", op->tag);
     if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
