@@ -78,29 +78,32 @@ def zero_page(device) -> torch.Tensor:
 
 
 def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
-    """(tile, splitk) for an implicit GEMM.  tile 1 = 128x128, 2 = 64x64.  Goal: >= ~1 wave of blocks over the 256
-    CUs; the low-resolution levels (M = 128..2048 tokens, K up to 23 040) get there by splitting K (>= 16
-    pipeline stages = 512 K-elements per split) instead of shrinking the tile."""
+    """(tile, splitk, variant) for an implicit GEMM, from the on-GPU sweep (tools/igemm_sweep.py, profiles/r1b_igemm_sweep.txt).
+    tile 1 = 128x128, 2 = 64x64; variant = pipeline shape (igemm.hip launch_p).  These kernels are occupancy /
+    latency bound, not DMA-depth bound: what matters is >= ~1.5 waves of blocks over the 256 CUs.
+      * >= 384 big tiles: 128x128 (3 blocks/CU with the 48 KB BK32x3 ring when there are >= 768 tiles);
+      * otherwise 64x64 tiles if that yields >= 256 blocks;
+      * otherwise (low-resolution levels: M = 128..2048 tokens, K up to 23 040) split K over 128x128 tiles
+        (>= 8 BK64 steps per split, K >= 2048), reduced by igemm_splitk_epilogue."""
     cdiv = lambda a, b: (a + b - 1) // b
-    nk = Kp // 32
+    nk64 = Kp // 64
     big = cdiv(Nout, 128) * cdiv(M, 128) * batch
-    if big >= 192:
-        return 1, 1
-    can_split = epi != 1
-    if can_split:
-        s_big = max(1, min(nk // 16, round(256 / big), 64))
-        if s_big >= 2 and big * s_big >= 128:
-            return 1, s_big
     small = cdiv(Nout, 64) * cdiv(M, 64) * batch
-    s_small = max(1, min(nk // 16, round(512 / small), 64)) if can_split else 1
-    if small >= 384:
-        s_small = 1
-    return 2, s_small
+    if big >= 384:
+        return 1, 1, (4 if big >= 768 else 5)
+    if small >= 256 or epi == 1:
+        return 2, 1, 5
+    if nk64 >= 32:
+        s_big = max(1, min(nk64 // 8, round(256 / big), 64))
+        if s_big >= 2:
+            return 1, s_big, 5
+    return 2, 1, 5
 
 
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
-          batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None):
+          batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
+          variant=5):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
     splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
@@ -123,7 +126,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     if splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
-            rows_per_bias, epi, batch, splitk, tile]
+            rows_per_bias, epi, batch, splitk, tile, variant]
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)

@@ -271,11 +271,11 @@ class HipStreamingUNet:
             """igemm with the (tile, split-K) schedule chosen for its shape; the fp32 split-K workspace comes from
             the arena and is released right after (stream order makes the reuse safe)."""
             batch, taps = kw.get("batch", 1), kw.get("taps", 1)
-            tile, S = ops.igemm_schedule(kw["M"], kw["Nout"], taps * kw["CinP"], batch, kw.get("epi", 0))
+            tile, S, variant = ops.igemm_schedule(kw["M"], kw["Nout"], taps * kw["CinP"], batch, kw.get("epi", 0))
             if self.igemm_splitk_off:
                 S = 1
             ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
-            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, **kw))
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
             ar.release(ws)
             return op
 

@@ -134,7 +134,7 @@ def test_igemm_schedule_matches_plain(L):
     x = rnd(B, H, W, cin, seed=1).to(DEV)
     wp = L.pack_conv3x3(rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5).to(DEV))
     M = B * H * W
-    tile, S = igemm_schedule(M, cout, wp.shape[1], 1, 0)
+    tile, S, _v = igemm_schedule(M, cout, wp.shape[1], 1, 0)
     assert S > 1
     outs = []
     for (t_, s_) in ((2, 1), (tile, S), (1, 3)):

@@ -57,7 +57,7 @@ def main():
         flops = 2.0 * M * cout * taps * cin
         base = None
         rows = []
-        auto_tile, auto_s = ops.igemm_schedule(M, cout, taps * cinp, 1, epi)
+        auto_tile, auto_s, auto_v = ops.igemm_schedule(M, cout, taps * cinp, 1, epi)
         cands = set()
         for tile in (1, 2):
             for s in {1, auto_s, 2, 4, 8}:
@@ -98,7 +98,7 @@ def main():
         print(f"\n== {name}   (schedule: tile {auto_tile} splitK {auto_s})")
         for variant, tile, s, us, info in rows:
             mark = " <== best" if us == best else ""
-            sched = " [sched]" if (tile, s) == (auto_tile, auto_s) and variant == 0 else ""
+            sched = " [sched]" if (tile, s, variant) == (auto_tile, auto_s, auto_v) else ""
             print(f"   {VARIANTS[variant]:7s} tile{'128' if tile == 1 else ' 64'} S{s:<2d} {us:8.1f} us  {info}{sched}{mark}")
 
 
