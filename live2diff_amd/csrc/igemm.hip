@@ -13,20 +13,25 @@
 //     loads in the epilogue; for GEGLU the value and gate columns (interleaved by 16 at pack time) land
 //     in the same lane.
 //   * 256 threads = 4 waves (2x2), block tile TN x TM (128x128 or 64x64).
-//   * Operand staging is LDS-DMA: `global_load_lds_dwordx4` (16 B/lane, no VGPR round trip), a 4-stage
-//     ring of BK = 32 slices (64 KB for the 128x128 tile -> 2 blocks/CU, 32 KB for 64x64), three stages in
-//     flight while one is on the matrix cores, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so the DMA
-//     queue is never drained inside the loop (one barrier per K step).  Round-1's register-staged,
-//     one-tile-ahead loop was latency bound (1.8 us per K step at 1 block/CU, rocprof r2).
+//   * Operand staging is LDS-DMA: `global_load_lds_dwordx4` (16 B/lane, no VGPR round trip) into a ring of
+//     NS stages of BK K-elements (default BK = 64 x 2 stages: 64 KB for the 128x128 tile -> 2 blocks/CU, 32 KB
+//     for 64x64), counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so the DMA queue is never drained inside the
+//     loop (one barrier per K step).  Round-1a's register-staged loop was latency bound (rocprof r1a); the
+//     on-GPU sweep (profiles/r1b_igemm_sweep.txt) showed the kernel is then insensitive to ring depth and bound
+//     by per-stage issue work, so BK = 64 (half the barriers / DMA instructions of BK = 32) is the default.
 //   * The LDS image of a DMA is lane-linear (wave-uniform base + 16*lane), so the bank swizzle is applied on
-//     the SOURCE side: lane l of a 16-row group fetches logical 16-byte slot (l&3) ^ ((row>>1)&3) of its row
-//     and the fragment reads apply the same XOR -> conflict-free ds_read_b128 (simulated against the gfx950
-//     lane-group table).  Conv zero padding / ragged rows / channel tails read from a 16-byte zero page.
+//     the SOURCE side: a lane fetches logical 16-byte slot  pslot ^ swz(row)  of its row and the fragment
+//     reads apply the same XOR -> conflict-free ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0 in the PMC pass).
+//     Conv zero padding / ragged rows / channel tails read from a 16-byte zero page.
+//   * PMC (profiles/r1b_pmc.txt) showed ~12 VALU + 7 SALU instructions per MFMA, i.e. the loop was bound by
+//     the gather's address arithmetic, not by the matrix cores.  The gather is therefore reduced to one 64-bit
+//     add + select per row per stage: per-row element offsets and a 9-bit tap-validity mask are computed once,
+//     the per-stage part (tap offset, channel offset) is wave-uniform scalar work.  Nearest-upsample convs and
+//     3x3 convs over a two-input concat use the generic (slower) gather.
 //   * Split-K (grid.y) for the low-resolution levels (M = 128..2048, K up to 23 040): fp32 partial tiles to a
 //     workspace, reduced by `igemm_splitk_epilogue` which applies the same fused epilogue.
 //   * XCD-aware block order: consecutive tiles (same token tile, neighbouring weight tiles) land on one XCD.
 #include "common.h"
-
 
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -77,7 +82,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
     *reinterpret_cast<h16x4 *>(outp + (long long)m * a.ldo + n) = o;
 }
 
-template <int TN, int TM, int TAPS, int BK, int NS>
+// MODE 0: linear / 1x1 (taps = 1);  MODE 1: 3x3, single input, no upsample (fast gather);  MODE 2: 3x3 generic
+template <int TN, int TM, int MODE, int BK, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     constexpr int NI = TN / 32;        // 16-row fragments per wave along channels
     constexpr int MI = TM / 32;        // 16-col fragments per wave along tokens
@@ -116,84 +122,115 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     const h16 *resp = a.res ? a.res + z * a.sres : nullptr;
     const int Ctot = a.C1 + a.C2;
 
+    // split-K: this block owns K steps [kb, ke)
+    const int nk = a.Kp / BK;
+    const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
+    const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
+
     // ---- per-lane DMA descriptors.  Within an RPI-row group lane l serves row l/SPR, physical slot l%SPR.
     const int lrow = lane / SPR, pslot = lane % SPR;
-    const h16 *wsrc[NIW];
-    int wstep[NIW];
+    const h16 *wptr[NIW];      // advances by wadv (BK or 0) halfs per stage
+    int wadv[NIW];
 #pragma unroll
     for (int j = 0; j < NIW; ++j) {
         const int r = (j * 4 + wave) * RPI + lrow;
         const int ls = pslot ^ swz(r);
         const int n = n0 + r;
         const bool ok = n < a.Nout;
-        wsrc[j] = ok ? wp + (long long)n * a.Kp + ls * 8 : a.zero;
-        wstep[j] = ok ? 1 : 0;
+        wptr[j] = ok ? wp + (long long)n * a.Kp + ls * 8 + (long long)kb * BK : a.zero;
+        wadv[j] = ok ? BK : 0;
     }
-    int xb[NIX], xy[NIX], xx[NIX], xls[NIX];
-    bool xv[NIX];
+    // token rows: xoff = element offset of (row, channel slot) from x1 for tap (0,0) [MODE 1] / for k = 0 [MODE 0]
+    long long xoff[NIX];
+    int xls[NIX], xmask[NIX];          // xmask: bit t = tap t in bounds (MODE 1); bit 0 = row valid (MODE 0)
+    int xb[NIX], xy[NIX], xx[NIX];     // MODE 2 only
 #pragma unroll
     for (int j = 0; j < NIX; ++j) {
         const int r = (j * 4 + wave) * RPI + lrow;
         xls[j] = (pslot ^ swz(r)) * 8;
         const int m = m0 + r;
-        xv[j] = m < a.M;
-        if (TAPS == 9) {
+        const bool rv = m < a.M;
+        xb[j] = xy[j] = xx[j] = 0;
+        if (MODE == 0) {
+            xoff[j] = (long long)m * a.ldx1 + xls[j];
+            xmask[j] = rv ? 1 : 0;
+            xb[j] = m;
+        } else {
             const int hw = a.Hout * a.Wout;
             const int b = m / hw, rr = m - b * hw;
-            xb[j] = b;
-            xy[j] = rr / a.Wout;
-            xx[j] = rr - xy[j] * a.Wout;
-        } else {
-            xb[j] = m; xy[j] = 0; xx[j] = 0;
+            const int oy = rr / a.Wout, ox = rr - oy * a.Wout;
+            xb[j] = b; xy[j] = oy; xx[j] = ox;
+            const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
+            xoff[j] = (((long long)b * a.Hin + iy0) * a.Win + ix0) * a.ldx1 + xls[j];
+            int mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                if (rv && iy >= 0 && ix >= 0 && iy < a.Hin && ix < a.Win) mk |= 1 << t;
+            }
+            xmask[j] = mk;
         }
     }
 
-    // split-K: this block owns K steps [kb, ke)
-    const int nk = a.Kp / BK;
-    const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
-    const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
-
     // issue() is called for consecutive stages kb, kb+1, ...: ring slot, k offset and the conv tap are tracked
-    // incrementally (no division / modulo in the loop)
-    int is_slot = 0, is_k0 = kb * BK, is_tap = 0, is_cb = kb * BK;
-    if (TAPS == 9) {
-        is_tap = is_k0 / a.CinP;
-        is_cb = is_k0 - is_tap * a.CinP;
+    // incrementally (no division / modulo in the loop); everything except the final add/select is wave-uniform
+    int is_slot = 0, is_tap = 0, is_cb = kb * BK;
+    if (MODE != 0) {
+        is_tap = (kb * BK) / a.CinP;
+        is_cb = kb * BK - is_tap * a.CinP;
     }
     auto issue = [&]() {
         h16 *st = smem + is_slot * STAGE;
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
             const int grp = j * 4 + wave;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(wsrc[j] + (long long)wstep[j] * is_k0), L2D_LPTR(st + grp * RPI * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(wptr[j]), L2D_LPTR(st + grp * RPI * BK), 16, 0, 0);
+            wptr[j] += wadv[j];
         }
-        int ky = 0, kx = 0;
-        if (TAPS == 9) {
-            ky = (is_tap * 11) >> 5;          // tap / 3 for tap in [0, 9)
-            kx = is_tap - ky * 3;
-        }
+        if (MODE == 0) {
+            const bool two = a.C2 > 0;
 #pragma unroll
-        for (int j = 0; j < NIX; ++j) {
-            const int grp = j * 4 + wave;
-            const int c = is_cb + xls[j];
-            bool ok = xv[j] && c < Ctot;
-            long long pix;
-            if (TAPS == 9) {
+            for (int j = 0; j < NIX; ++j) {
+                const int grp = j * 4 + wave;
+                const int c = is_cb + xls[j];
+                const h16 *src = a.zero;
+                if (xmask[j]) {
+                    if (c < a.C1) src = x1 + xoff[j] + is_cb;
+                    else if (two && c < Ctot) src = a.x2 + (long long)xb[j] * a.ldx2 + (c - a.C1);
+                }
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * RPI) * BK), 16, 0, 0);
+            }
+        } else if (MODE == 1) {
+            const int ky = (is_tap * 11) >> 5;          // tap / 3 for tap in [0, 9)
+            const int kx = is_tap - ky * 3;
+            const long long uoff = (long long)(ky * a.Win + kx) * a.ldx1 + is_cb;   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < NIX; ++j) {
+                const int grp = j * 4 + wave;
+                const bool ok = ((xmask[j] >> is_tap) & 1) && (is_cb + xls[j] < a.C1);
+                const h16 *src = ok ? x1 + xoff[j] + uoff : a.zero;
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * RPI) * BK), 16, 0, 0);
+            }
+        } else {
+            const int ky = (is_tap * 11) >> 5;
+            const int kx = is_tap - ky * 3;
+#pragma unroll
+            for (int j = 0; j < NIX; ++j) {
+                const int grp = j * 4 + wave;
+                const int c = is_cb + xls[j];
                 const int iy = xy[j] * a.stride + ky - 1;
                 const int ix = xx[j] * a.stride + kx - 1;
-                ok = ok && iy >= 0 && ix >= 0 && iy < (a.Hin << a.ups) && ix < (a.Win << a.ups);
-                pix = ((long long)xb[j] * a.Hin + (iy >> a.ups)) * a.Win + (ix >> a.ups);
-            } else {
-                pix = xb[j];
+                const bool ok = (m0 + (j * 4 + wave) * RPI + lrow < a.M) && c < Ctot && iy >= 0 && ix >= 0 &&
+                                iy < (a.Hin << a.ups) && ix < (a.Win << a.ups);
+                const long long pix = ((long long)xb[j] * a.Hin + (iy >> a.ups)) * a.Win + (ix >> a.ups);
+                const h16 *src = a.zero;
+                if (ok) src = (c < a.C1) ? x1 + pix * a.ldx1 + c : a.x2 + pix * a.ldx2 + (c - a.C1);
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * RPI) * BK), 16, 0, 0);
             }
-            const h16 *src = a.zero;
-            if (ok) src = (c < a.C1) ? x1 + pix * a.ldx1 + c : a.x2 + pix * a.ldx2 + (c - a.C1);
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + (TN + grp * RPI) * BK), 16, 0, 0);
         }
         is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
-        is_k0 += BK;
         is_cb += BK;
-        if (TAPS == 9 && is_cb >= a.CinP) { is_cb -= a.CinP; ++is_tap; }
+        if (MODE != 0 && is_cb >= a.CinP) { is_cb -= a.CinP; ++is_tap; }
     };
 
     f32x4 acc[NI][MI];
@@ -202,6 +239,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // fragment read offsets are loop invariant (halfs, relative to the stage base)
+    int aoff[KK][NI], boff[KK][MI];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = wn * (TN / 2) + i * 16 + li;
+            aoff[kk][i] = r * BK + (((kk * 4 + lg) ^ swz(r)) << 3);
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const int r = wm * (TM / 2) + j * 16 + li;
+            boff[kk][j] = (TN + r) * BK + (((kk * 4 + lg) ^ swz(r)) << 3);
+        }
+    }
     int cp_slot = 0;
     auto compute = [&]() {
         const h16 *st = smem + cp_slot * STAGE;
@@ -209,15 +261,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         for (int kk = 0; kk < KK; ++kk) {
             h16x8 af[NI], bf[MI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int r = wn * (TN / 2) + i * 16 + li;
-                af[i] = l2d_ld8(st + r * BK + (((kk * 4 + lg) ^ swz(r)) << 3));
-            }
+            for (int i = 0; i < NI; ++i) af[i] = l2d_ld8(st + aoff[kk][i]);
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int r = wm * (TM / 2) + j * 16 + li;
-                bf[j] = l2d_ld8(st + (TN + r) * BK + (((kk * 4 + lg) ^ swz(r)) << 3));
-            }
+            for (int j = 0; j < MI; ++j) bf[j] = l2d_ld8(st + boff[kk][j]);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -317,36 +363,39 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
     igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
 }
 
-template <int TN, int TM, int TAPS, int BK, int NS>
+template <int TN, int TM, int MODE, int BK, int NS>
 static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
     constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
     static bool attr_done = false;
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, TAPS, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_done = true;
     }
     int ntn = (a.Nout + TN - 1) / TN, ntm = (a.M + TM - 1) / TM;
     dim3 grid(ntn * ntm, a.splitk, batch), block(256);
-    hipLaunchKernelGGL((igemm_kernel<TN, TM, TAPS, BK, NS>), grid, block, LDS, s, a);
+    hipLaunchKernelGGL((igemm_kernel<TN, TM, MODE, BK, NS>), grid, block, LDS, s, a);
 }
 
-// pipeline variants (op.i[23]): 0 = BK32 x 4 stages (default), 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3, 5 = BK64 x 2
-template <int TN, int TM, int TAPS>
+// pipeline variants (op.i[23]): 0 = BK32 x 4 stages, 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3,
+// 5 = BK64 x 2 (default)
+template <int TN, int TM, int MODE>
 static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
     switch (variant) {
-        case 0: launch_v<TN, TM, TAPS, 32, 4>(a, batch, s); return L2D_OK;
-        case 1: launch_v<TN, TM, TAPS, 64, 3>(a, batch, s); return L2D_OK;
-        case 2: launch_v<TN, TM, TAPS, 64, 4>(a, batch, s); return L2D_OK;
-        case 3: launch_v<TN, TM, TAPS, 32, 6>(a, batch, s); return L2D_OK;
-        case 4: launch_v<TN, TM, TAPS, 32, 3>(a, batch, s); return L2D_OK;
-        case 5: launch_v<TN, TM, TAPS, 64, 2>(a, batch, s); return L2D_OK;
+        case 0: launch_v<TN, TM, MODE, 32, 4>(a, batch, s); return L2D_OK;
+        case 1: launch_v<TN, TM, MODE, 64, 3>(a, batch, s); return L2D_OK;
+        case 2: launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK;
+        case 3: launch_v<TN, TM, MODE, 32, 6>(a, batch, s); return L2D_OK;
+        case 4: launch_v<TN, TM, MODE, 32, 3>(a, batch, s); return L2D_OK;
+        case 5: launch_v<TN, TM, MODE, 64, 2>(a, batch, s); return L2D_OK;
     }
     return L2D_EINVAL;
 }
 
 template <int TN, int TM>
 static int launch_t(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
-    return a.taps == 9 ? launch_p<TN, TM, 9>(a, batch, variant, s) : launch_p<TN, TM, 1>(a, batch, variant, s);
+    if (a.taps == 1) return launch_p<TN, TM, 0>(a, batch, variant, s);
+    if (a.C2 == 0 && a.ups == 0) return launch_p<TN, TM, 1>(a, batch, variant, s);
+    return launch_p<TN, TM, 2>(a, batch, variant, s);
 }
 
 int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
@@ -360,7 +409,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.ldo = op->i[15]; a.ldr = op->i[16]; a.ldrb = op->i[17]; a.rows_per_bias = op->i[18]; a.epi = op->i[19];
     int batch = op->i[20] > 0 ? op->i[20] : 1;
     a.splitk = op->i[21] > 0 ? op->i[21] : 1;
-    int tile = op->i[22];   // 0 auto, 1 = 128x128, 2 = 64x64
+    int tile = op->i[22];      // 0 auto, 1 = 128x128, 2 = 64x64
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.Kp = a.taps * a.CinP;
@@ -369,8 +418,8 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1)) || (a.stride != 1 && a.stride != 2) ||
-        (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 || variant < 0 || variant > 5 ||
-        a.splitk > 64) {
+        (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
+        variant < 0 || variant > 5 || a.splitk > 64) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
         return L2D_EINVAL;
@@ -381,9 +430,8 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     }
     L2D_DRY_RETURN();
     if (tile == 0) {
-        // the big tile only when it still yields >= ~1 wave of blocks over 256 CUs
         long long big = (long long)((a.Nout + 127) / 128) * ((a.M + 127) / 128) * batch * a.splitk;
-        tile = (big >= 192) ? 1 : 2;
+        tile = (big >= 384) ? 1 : 2;
     }
     if (tile == 1) launch_t<128, 128>(a, batch, variant, s);
     else launch_t<64, 64>(a, batch, variant, s);

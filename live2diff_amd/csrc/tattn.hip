@@ -255,6 +255,8 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB), lds, s, a);
     else if (v == 3)
         hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, 4>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 4 && L % 16 == 0)   // all K rows, then all V rows in flight (16 loads/thread), ~3 blocks/CU
+        hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, (L % 16 == 0 ? 16 : 4)>), dim3(nb), dim3(TP * PB), lds, s, a);
     else
         hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, (L % 8 == 0 ? 8 : 4)>), dim3(nb), dim3(TP * PB), lds, s, a);
     return L2D_OK;
