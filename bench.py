@@ -289,7 +289,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(name)
+            traffic = (json.load(open(tpath)).get(name) or {}).get("hbm_bytes_per_launch")
         if name in ("igemm_kernel", "flash_attn_kernel"):
             ach = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12
             result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
@@ -304,7 +304,8 @@ def main():
             ach = t["bytes"] / (t["ms"] * 1e-3) / 1e9
             result["roofline_kv_cache_kernel"] = {"kernel": "tattn_stream_kernel", "bound": "hbm", "achieved": round(ach, 1),
                                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                                                  "traffic": (json.load(open(tpath)).get("tattn_stream_kernel") if os.path.exists(tpath) else None)}
+                                                  "traffic": ((json.load(open(tpath)).get("tattn_stream_kernel") or {}).get("hbm_bytes_per_launch")
+                                                              if os.path.exists(tpath) else None)}
         # measured copy bandwidth for context
         try:
             import ctypes

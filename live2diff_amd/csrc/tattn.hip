@@ -390,11 +390,11 @@ __global__ __launch_bounds__(TP *PB) void tattn_warmup_kernel(TAttnArgs a) {
 }
 
 template <int TP, int PB>
-static int launch_warm_t(const TAttnArgs &a, hipStream_t s) {
-    constexpr int F = 8;
+static int launch_warm_t(const TAttnArgs &a, int F, hipStream_t s) {
     int nb = (a.T + PB - 1) / PB;
     size_t lds = (size_t)TP * PB * (F * F + 4) * sizeof(float);
-    hipLaunchKernelGGL((tattn_warmup_kernel<TP, PB, F>), dim3(nb), dim3(TP * PB), lds, s, a);
+    if (F == 8) hipLaunchKernelGGL((tattn_warmup_kernel<TP, PB, 8>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else hipLaunchKernelGGL((tattn_warmup_kernel<TP, PB, 4>), dim3(nb), dim3(TP * PB), lds, s, a);
     return L2D_OK;
 }
 
@@ -403,19 +403,19 @@ int l2d_launch_tattn_warmup(const l2d_op *op, hipStream_t s) {
     int rc = tattn_common(op, a, "tattn_warmup");
     if (rc) return rc;
     int F = a.N;  // i0 carries the number of warm-up frames
-    if (F != 8 || F > a.L) {
-        l2d_set_error("tattn_warmup(tag %d): F=%d unsupported (built: F=8 <= L)", op->tag, F);
+    if ((F != 8 && F != 4) || F > a.L) {
+        l2d_set_error("tattn_warmup(tag %d): F=%d unsupported (built: F in {4, 8}, F <= L)", op->tag, F);
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
-    // a block stages F*F partial scores per thread in LDS (272 B/thread): blocks of <= 160 threads
+    // a block stages F*F partial scores per thread in LDS (272 B/thread at F=8): blocks of <= 160 threads
     switch (a.C) {
-        case 64: rc = launch_warm_t<8, 16>(a, s); break;
-        case 128: rc = launch_warm_t<16, 8>(a, s); break;
-        case 256: rc = launch_warm_t<32, 4>(a, s); break;
-        case 320: rc = launch_warm_t<40, 4>(a, s); break;
-        case 640: rc = launch_warm_t<80, 2>(a, s); break;
-        case 1280: rc = launch_warm_t<160, 1>(a, s); break;
+        case 64: rc = launch_warm_t<8, 16>(a, F, s); break;
+        case 128: rc = launch_warm_t<16, 8>(a, F, s); break;
+        case 256: rc = launch_warm_t<32, 4>(a, F, s); break;
+        case 320: rc = launch_warm_t<40, 4>(a, F, s); break;
+        case 640: rc = launch_warm_t<80, 2>(a, F, s); break;
+        case 1280: rc = launch_warm_t<160, 1>(a, F, s); break;
         default:
             l2d_set_error("tattn_warmup(tag %d): unsupported C=%d", op->tag, a.C);
             return L2D_EINVAL;

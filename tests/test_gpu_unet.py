@@ -33,7 +33,8 @@ def _rollout(cfg, h, w, N, frames, golden, use_graph=False, gain=1.0):
     from live2diff_amd.weights import random_state_dict
     from oracle import unet_ref as O
 
-    sm = golden("state_machine")
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)     # == the reference trace (tests/test_host_logic.py)
     sd = random_state_dict(cfg, dtype=torch.float16, gain=gain)           # both sides see the fp16-rounded weights
     sd32 = {k: v.float() for k, v in sd.items()}
     unet = HipStreamingUNet({k: v.to(DEV) for k, v in sd.items()}, cfg, h, w, N, use_graph=use_graph)
@@ -55,12 +56,9 @@ def _rollout(cfg, h, w, N, frames, golden, use_graph=False, gain=1.0):
         report.append(("warmup", idx, rel(out, ref), cos(out, ref)))
     kvr = max(rel(a, b) for a, b in zip(kv, kv_ref))
     report.append(("cache-after-warmup", 0, kvr, 1.0))
-    key = f"n{N}"
     for f in range(frames):
         x, d = rnd(N, 4, 1, h, w, seed=800 + f).half(), rnd(N, 4, 1, h, w, seed=900 + f).half()
-        bias = torch.from_numpy(sm["bias_" + key])[f]
-        pe_idx = torch.from_numpy(sm["pe_idx_" + key])[f]
-        upd = torch.from_numpy(sm["update_idx_" + key])[f]
+        bias, pe_idx, upd = rb[0].clone(), rb[1].clone(), rb[2].clone()
         ref = O.unet_forward(sd32, cfg, x.float(), ts, enc.float().repeat(N, 1, 1), d.float(), kv_ref,
                              temporal_attention_mask=bias, pe_idx=pe_idx, update_idx=upd)
         o = unet(x.to(DEV), ts.to(DEV), encoder_hidden_states=enc.repeat(N, 1, 1).to(DEV),
@@ -71,6 +69,7 @@ def _rollout(cfg, h, w, N, frames, golden, use_graph=False, gain=1.0):
         torch.cuda.synchronize()
         assert torch.isfinite(out).all()
         report.append(("stream", f, rel(out, ref), cos(out, ref)))
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
     kvr = max(rel(a, b) for a, b in zip(kv, kv_ref))
     report.append(("cache-final", 0, kvr, 1.0))
     return report, unet
@@ -99,6 +98,21 @@ def test_tiny_unet_rollout_n3_graph(golden):
     from live2diff_amd.config import tiny_config
     cfg = tiny_config(channels=(64, 128, 256, 256), cross_attention_dim=64)
     report, _ = _rollout(cfg, 16, 24, 3, 10, golden, use_graph=True)
+    _assert(report)
+
+
+@pytest.mark.parametrize("name,h,w,N,L,S,frames", [
+    ("cfg1-like: 1 step, 4-frame warm-up, L=12", 16, 16, 1, 12, 4, 12),
+    ("cfg3-like: 3:2 aspect, L=24", 16, 24, 2, 24, 8, 20),
+    ("cfg4-like: 4 steps", 16, 16, 4, 16, 8, 10),
+    ("cfg5-like: 16:9 aspect, L=40", 8, 16, 2, 40, 8, 36),
+])
+def test_other_baseline_configs_tiny(golden, name, h, w, N, L, S, frames):
+    """The window / step / aspect parameters of BASELINE.json configs 1, 3, 4, 5 at test widths: full warm-up +
+    enough streaming frames to wrap the rolling window, against the oracle."""
+    from live2diff_amd.config import tiny_config
+    cfg = tiny_config(window_size=L, sink_size=S, channels=(64, 128, 256, 256), cross_attention_dim=64)
+    report, _ = _rollout(cfg, h, w, N, frames, golden)
     _assert(report)
 
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 `--pmc` passes (rocpd SQLite databases) per kernel family.
+
+  python tools/pmc_summary.py <out.txt> <db> [<db> ...] [--traffic profiles/traffic.json]
+
+Prints, per kernel name, the average of every collected counter per dispatch.  With --traffic, HBM bytes per
+launch are derived from FETCH_SIZE / WRITE_SIZE (kB) exactly as MI355X_MICROARCH.md section HBM prescribes for
+gfx950: FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x -> read bytes = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is used as reported (uncalibrated); the two counters come from separate passes.
+"""
+import collections
+import json
+import sqlite3
+import sys
+
+PRODUCT = ("igemm", "gn_", "layernorm", "flash_attn", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step")
+
+
+def short(name):
+    n = name.replace("void ", "").split("(")[0]
+    if n.startswith("_Z"):
+        for p in PRODUCT:
+            if p in n:
+                return p.rstrip("_") + "_kernel" if not p.endswith("kernel") else p
+    return n
+
+
+def family(name):
+    for p in ("igemm_splitk_epilogue", "igemm_kernel", "gn_stats", "gn_apply", "layernorm", "flash_attn", "tattn_stream", "tattn_warmup",
+              "skinny_linear", "timestep_embed", "nchw_to_nhwc", "nhwc_to_nchw", "lcm_step"):
+        if p in name:
+            return p + ("_kernel" if not p.endswith("kernel") and p != "igemm_splitk_epilogue" else "")
+    return None
+
+
+def main():
+    args = sys.argv[1:]
+    traffic_path = None
+    if "--traffic" in args:
+        i = args.index("--traffic")
+        traffic_path = args[i + 1]
+        del args[i:i + 2]
+    out_path, dbs = args[0], args[1:]
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    fam = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for db in dbs:
+        c = sqlite3.connect(db)
+        rows = c.execute("select kernel_name, counter_name, value, dispatch_id, (end-start) from counters_collection").fetchall()
+        seen = set()
+        for k, cn, v, d, t in rows:
+            ks = short(k)
+            per_kernel[ks][cn].append(v)
+            f = family(k)
+            if f:
+                fam[f][cn].append(v)
+            if (db, d) not in seen:
+                seen.add((db, d))
+                dur[ks].append(t / 1e3)
+    with open(out_path, "w") as f:
+        for ks in sorted(per_kernel, key=lambda k: -sum(dur[k])):
+            if not any(p in ks for p in PRODUCT):
+                continue
+            d = dur[ks]
+            f.write(f"{ks}\n    dispatches(all passes)={len(d)} avg_us={sum(d) / len(d):.2f}\n")
+            for cn, v in sorted(per_kernel[ks].items()):
+                f.write(f"    {cn:34s} avg/dispatch = {sum(v) / len(v):.6g}\n")
+    if traffic_path:
+        tr = {}
+        for k, ctr in fam.items():
+            if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                rd = 2.0 * 1024.0 * sum(ctr["FETCH_SIZE"]) / len(ctr["FETCH_SIZE"])
+                wr = 1024.0 * sum(ctr["WRITE_SIZE"]) / len(ctr["WRITE_SIZE"])
+                tr[k] = {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr),
+                         "launches_sampled": len(ctr["FETCH_SIZE"]),
+                         "note": "FETCH_SIZE*1024*2 (gfx950 16B/lane correction) + WRITE_SIZE*1024; separate --pmc passes"}
+        with open(traffic_path, "w") as f:
+            json.dump(tr, f, indent=1, sort_keys=True)
+    print("wrote", out_path, traffic_path or "")
+
+
+if __name__ == "__main__":
+    main()
