@@ -98,7 +98,7 @@ def tattn_variant_sweep(unet, reps=5):
     st = unet._plans["stream"]
     src = [st.pl[j] for j in range(len(st.pl)) if st.pl[j].kind == _lib.OP_TATTN_STREAM]
     lists = {}
-    for v in (1, 2, 4):
+    for v in (1, 6, 7):
         pl = _lib.OpList()
         for op in src:
             c = _lib.L2dOp()

@@ -35,11 +35,11 @@ __device__ __forceinline__ float dot8(h16x8 a, h16x8 b) {
     return s;
 }
 
-template <int TP, int PB, int L>
+template <int TP, int PB, int L, bool PV = true>
 __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
     constexpr int HG = TP / 8;  // threads per head (= d/8)
     constexpr int LP = L + 4;   // padded LDS row (floats)
-    constexpr bool PRELOAD_V = (L <= 24);
+    constexpr bool PRELOAD_V = PV && (L <= 24);   // V rows in flight together with the K rows
     extern __shared__ __attribute__((aligned(16))) float sp[];  // [PB*TP][LP]
 
     const int tid = threadIdx.x;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) s[l] = 0.f;
     const int gs = p * TP + (cc / HG) * HG;
+#pragma unroll 2
     for (int j = 0; j < HG; ++j) {
         const float *r = sp + (long long)(gs + j) * LP;
 #pragma unroll
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
 #pragma unroll
     for (int l = 0; l < L; ++l) { s[l] = __expf(s[l] - mx); den += s[l]; }
     const float inv = 1.0f / den;
+    const h16 *vc_late = vc;
+    if (!PRELOAD_V) asm volatile("" : "+v"(vc_late));   // keeps the V loads below the barrier (bounded registers)
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
@@ -120,9 +123,131 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
             vv = vreg[l];
         } else {
             vv = v8;
-            if (l != u) vv = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+            if (l != u) vv = live ? l2d_ld8(vc_late + (long long)l * C) : l2d_zero8();
         }
         vv = vv + l2d_ld8(a.v_pe + pei[l] * C + cc * 8);     // (:141)
+        const float pl = s[l] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pl * (float)vv[e];
+    }
+    if (valid) {
+        h16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+        l2d_st8(a.out + pix * C + cc * 8, ov);
+    }
+}
+
+// Variant with the gathered positional-encoding rows (k_pe / v_pe [pe_idx[n,l]]) staged ONCE per block in LDS
+// instead of being re-fetched by every thread for every slot: halves the global-load instruction count and
+// frees the 2 x 64 VGPRs those loads kept in flight, so K and V rows (2L x 16 B per thread) fit ~170 VGPRs and
+// two 320-thread blocks share a CU (the loads of one overlap the reduction / store phase of the other).
+// LDS: [PB*TP][L+4] fp32 partial scores | k_pe rows [L][C] | v_pe rows [L][C] halfs.
+template <int TP, int PB, int L>
+__global__ __launch_bounds__(TP *PB) void tattn_stream_lds_kernel(TAttnArgs a) {
+    constexpr int HG = TP / 8;
+    constexpr int LP = L + 4;
+    constexpr int C = TP * 8;
+    extern __shared__ __attribute__((aligned(16))) float sp[];
+    h16 *pek = reinterpret_cast<h16 *>(sp + TP * PB * LP);
+    h16 *pev = pek + L * C;
+
+    const int tid = threadIdx.x;
+    const int p = tid / TP, cc = tid - p * TP;
+    const long long NT = (long long)a.N * a.T;
+    const long long pix0 = (long long)blockIdx.x * PB;
+    const long long pix = pix0 + p;
+    const bool valid = pix < NT;
+    const int n = valid ? (int)(pix / a.T) : 0;
+    const int n_blk = (int)(pix0 / a.T);            // the PE rows staged in LDS are those of the block's first pixel
+    const long long t = valid ? pix - (long long)n * a.T : 0;
+    const int u = (int)a.update_idx[n];
+    const long long *pei = a.pe_idx + (long long)n * L;
+    const h16 *bi = a.bias + (long long)n * L;
+
+    h16x8 q8 = l2d_zero8(), k8 = l2d_zero8(), v8 = l2d_zero8();
+    h16 *kc = a.cache + (((long long)n * 2 + 0) * a.T + t) * L * C + cc * 8;
+    h16 *vc = a.cache + (((long long)n * 2 + 1) * a.T + t) * L * C + cc * 8;
+    if (valid) {
+        const h16 *src = a.qkv + pix * 3 * C + cc * 8;
+        q8 = l2d_ld8(src);
+        k8 = l2d_ld8(src + C);
+        v8 = l2d_ld8(src + 2 * C);
+        q8 = q8 + l2d_ld8(a.q_pe + pei[u] * C + cc * 8);
+        l2d_st8(kc + (long long)u * C, k8);
+        l2d_st8(vc + (long long)u * C, v8);
+    }
+    // all K and V rows of this thread in flight (masked slots are never read: live-mask in one register)
+    unsigned livemask = 0;
+    h16x8 kreg[L], vreg[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const bool live = valid && (float)bi[l] > -1e30f;
+        livemask |= live ? (1u << l) : 0u;
+        kreg[l] = k8;
+        vreg[l] = v8;
+        if (l != u) {
+            kreg[l] = live ? l2d_ld8(kc + (long long)l * C) : l2d_zero8();
+            vreg[l] = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+        }
+    }
+    // stage the gathered PE rows (L2 resident, 2 x L x C halfs) while the cache rows are in flight
+    {
+        const long long *peb = a.pe_idx + (long long)n_blk * L;
+        for (int idx = tid; idx < L * TP; idx += TP * PB) {
+            const int l = idx / TP, c8 = idx - l * TP;
+            const long long row = peb[l] * C + c8 * 8;
+            l2d_st8(pek + l * C + c8 * 8, l2d_ld8(a.k_pe + row));
+            l2d_st8(pev + l * C + c8 * 8, l2d_ld8(a.v_pe + row));
+        }
+    }
+    __syncthreads();
+    const bool pe_lds = (n == n_blk);               // a block straddling two denoise rows falls back to global PE
+    float *row = sp + (long long)tid * LP;
+#pragma unroll
+    for (int l = 0; l < L; l += 4) {
+        f32x4 pr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const h16x8 pe = pe_lds ? l2d_ld8(pek + (l + r) * C + cc * 8) : l2d_ld8(a.k_pe + pei[l + r] * C + cc * 8);
+            pr[r] = dot8(q8, kreg[l + r] + pe);      // fp16 rounding of K+pe as in the reference (:140)
+        }
+        *reinterpret_cast<f32x4 *>(row + l) = pr;
+    }
+    __syncthreads();
+    float s[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) s[l] = 0.f;
+    const int gs = p * TP + (cc / HG) * HG;
+#pragma unroll 2
+    for (int j = 0; j < HG; ++j) {
+        const float *r = sp + (long long)(gs + j) * LP;
+#pragma unroll
+        for (int l = 0; l < L; l += 4) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>(r + l);
+            s[l] += x[0]; s[l + 1] += x[1]; s[l + 2] += x[2]; s[l + 3] += x[3];
+        }
+    }
+    const float scale = rsqrtf((float)(C / a.H));
+    float mx = -3.0e38f;
+    const h16 *bi_late = bi;
+    asm volatile("" : "+v"(bi_late));   // re-read the (L1-resident) bias row here instead of holding L floats since kernel entry
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        s[l] = s[l] * scale + (float)bi_late[l];
+        mx = fmaxf(mx, s[l]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { s[l] = __expf(s[l] - mx); den += s[l]; }
+    const float inv = 1.0f / den;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const h16x8 pe = pe_lds ? l2d_ld8(pev + l * C + cc * 8) : l2d_ld8(a.v_pe + pei[l] * C + cc * 8);
+        const h16x8 vv = vreg[l] + pe;               // (:141)
         const float pl = s[l] * inv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += pl * (float)vv[e];
@@ -192,6 +317,7 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_chunked_kernel(TAttnArgs 
 #pragma unroll
     for (int l = 0; l < L; ++l) s[l] = 0.f;
     const int gs = p * TP + (cc / HG) * HG;
+#pragma unroll 2
     for (int j = 0; j < HG; ++j) {
         const float *r = sp + (long long)(gs + j) * LP;
 #pragma unroll
@@ -253,6 +379,17 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
     if (v == 0) v = (L <= 16) ? 1 : 2;
     if (v == 1 && L <= 16)
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 7 && L <= 16)   // PE rows staged in LDS
+        hipLaunchKernelGGL((tattn_stream_lds_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB),
+                           lds + (size_t)2 * L * TP * 8 * sizeof(h16), s, a);
+    else if (v == 5 && L <= 16)   // register resident, V loaded after the softmax: fewer VGPRs -> 2 blocks/CU
+        hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), false>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 6 && L <= 16 && PB >= 2) {   // half the pixels per block: more, smaller blocks
+        constexpr int PB2 = PB >= 2 ? PB / 2 : 1;
+        int nb2 = (int)((NT + PB2 - 1) / PB2);
+        hipLaunchKernelGGL((tattn_stream_kernel<TP, PB2, (L <= 16 ? L : 16)>), dim3(nb2), dim3(TP * PB2),
+                           (size_t)TP * PB2 * (L + 4) * sizeof(float), s, a);
+    }
     else if (v == 3)
         hipLaunchKernelGGL((tattn_stream_chunked_kernel<TP, PB, L, 4>), dim3(nb), dim3(TP * PB), lds, s, a);
     else if (v == 4 && L % 16 == 0)   // all K rows, then all V rows in flight (16 loads/thread), ~3 blocks/CU

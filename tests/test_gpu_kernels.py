@@ -281,7 +281,9 @@ def _tattn_case(C, T, Lw, S, N, seed, ramp=True):
 @pytest.mark.parametrize("C,T,Lw,S,N,variant", [(64, 16, 16, 8, 2, 0), (64, 50, 12, 4, 1, 0), (128, 8, 24, 8, 4, 0),
                                                 (64, 4, 40, 8, 2, 0), (320, 256, 16, 8, 2, 0), (320, 256, 16, 8, 2, 2),
                                                 (320, 100, 16, 8, 2, 3), (640, 64, 16, 8, 2, 0), (1280, 16, 16, 8, 2, 0),
-                                                (1280, 64, 40, 8, 2, 0), (256, 37, 24, 8, 3, 0)])
+                                                (1280, 64, 40, 8, 2, 0), (256, 37, 24, 8, 3, 0),
+                                                (320, 256, 16, 8, 2, 7), (640, 64, 16, 8, 2, 7), (1280, 16, 16, 8, 2, 7),
+                                                (64, 50, 12, 4, 1, 7), (256, 37, 16, 8, 3, 7), (320, 100, 16, 8, 2, 6)])
 def test_tattn_stream(L, C, T, Lw, S, N, variant):
     from live2diff_amd.config import tiny_config
     from oracle import unet_ref as O
