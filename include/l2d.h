@@ -138,6 +138,11 @@ int l2d_time_ops(const l2d_op *ops, int n, void *stream, int reps, float *ms_out
  * next to the datasheet number: copies `bytes` from src to dst `reps` times, returns GB/s (read+write). */
 int l2d_copy_bench(const void *src, void *dst, int64_t bytes, int reps, void *stream, float *gbps_out);
 
+/* HBM read probe: streaming 16-byte loads, `unroll` (1,2,4,8,16) independent loads in flight per thread,
+ * 256 x blocks_per_cu blocks of 256 threads; returns GB/s read. */
+int l2d_read_bench(const void *src, void *sink, int64_t bytes, int unroll, int blocks_per_cu, int reps, void *stream,
+                   float *gbps_out);
+
 #ifdef __cplusplus
 }
 #endif

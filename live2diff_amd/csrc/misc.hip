@@ -194,3 +194,56 @@ extern "C" int l2d_copy_bench(const void *src, void *dst, int64_t bytes, int rep
     *gbps_out = (float)(2.0 * (double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9);
     return l2d_check_launch("copy_bench", 0);
 }
+
+// ------------------------------------------------------------------------------------------- HBM read probe
+// Pure streaming read (xor-reduce so the loads cannot be dropped), U independent 16-byte loads in flight per
+// thread, blocks_per_cu resident blocks: measures what a read-dominated kernel such as the KV-cache attention
+// can expect from this part (the copy probe above spends half of its traffic on writes).
+template <int U>
+__global__ __launch_bounds__(256) void read_kernel(const f32x4 *__restrict__ src, unsigned *__restrict__ sink, long long n16) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= __float_as_uint(v[u][0]) ^ __float_as_uint(v[u][1]) ^ __float_as_uint(v[u][2]) ^ __float_as_uint(v[u][3]);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+extern "C" int l2d_read_bench(const void *src, void *sink, int64_t bytes, int unroll, int blocks_per_cu, int reps, void *stream,
+                              float *gbps_out) {
+    if (!src || !sink || bytes < 16 || reps <= 0 || !gbps_out || blocks_per_cu <= 0) {
+        l2d_set_error("read_bench: invalid arguments");
+        return L2D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    long long n16 = bytes / 16;
+    int grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto launch = [&]() {
+        switch (unroll) {
+            case 1: hipLaunchKernelGGL((read_kernel<1>), dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (unsigned *)sink, n16); break;
+            case 2: hipLaunchKernelGGL((read_kernel<2>), dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (unsigned *)sink, n16); break;
+            case 4: hipLaunchKernelGGL((read_kernel<4>), dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (unsigned *)sink, n16); break;
+            case 8: hipLaunchKernelGGL((read_kernel<8>), dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (unsigned *)sink, n16); break;
+            default: hipLaunchKernelGGL((read_kernel<16>), dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (unsigned *)sink, n16); break;
+        }
+    };
+    launch();
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbps_out = (float)((double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9);
+    return l2d_check_launch("read_bench", 0);
+}
