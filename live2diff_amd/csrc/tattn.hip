@@ -35,7 +35,9 @@ __device__ __forceinline__ float dot8(h16x8 a, h16x8 b) {
     return s;
 }
 
-template <int TP, int PB, int L, bool PV = true>
+// ABL (ablation builds for the on-GPU phase analysis only, selected by variants 8/9; results are NOT valid attention):
+//   1 = no cache loads (every slot uses the new row), 2 = no cross-thread score reduction.
+template <int TP, int PB, int L, bool PV = true, int ABL = 0>
 __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
     constexpr int HG = TP / 8;  // threads per head (= d/8)
     constexpr int LP = L + 4;   // padded LDS row (floats)
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
         bl[l] = (float)bi[l];
         const bool live = valid && bl[l] > -1e30f;
         h16x8 kk = k8;
-        if (l != u) kk = live ? l2d_ld8(kc + (long long)l * C) : l2d_zero8();
+        if (ABL != 1 && l != u) kk = live ? l2d_ld8(kc + (long long)l * C) : l2d_zero8();
         if (PRELOAD_V) {
             h16x8 vv = v8;
-            if (l != u) vv = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
+            if (ABL != 1 && l != u) vv = live ? l2d_ld8(vc + (long long)l * C) : l2d_zero8();
             vreg[l] = vv;
         }
         h16x8 pe = l2d_ld8(a.k_pe + pei[l] * C + cc * 8);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_kernel(TAttnArgs a) {
     for (int l = 0; l < L; ++l) s[l] = 0.f;
     const int gs = p * TP + (cc / HG) * HG;
 #pragma unroll 2
-    for (int j = 0; j < HG; ++j) {
+    for (int j = 0; j < (ABL == 2 ? 1 : HG); ++j) {
         const float *r = sp + (long long)(gs + j) * LP;
 #pragma unroll
         for (int l = 0; l < L; l += 4) {
@@ -379,6 +381,10 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
     if (v == 0) v = (L <= 16) ? 1 : 2;
     if (v == 1 && L <= 16)
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 8 && L <= 16)
+        hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), true, 1>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v == 9 && L <= 16)
+        hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), true, 2>), dim3(nb), dim3(TP * PB), lds, s, a);
     else if (v == 7 && L <= 16)   // PE rows staged in LDS
         hipLaunchKernelGGL((tattn_stream_lds_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB),
                            lds + (size_t)2 * L * TP * 8 * sizeof(h16), s, a);
