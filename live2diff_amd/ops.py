@@ -85,23 +85,24 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
       * otherwise 64x64 tiles if that yields >= 256 blocks;
       * otherwise (low-resolution levels: M = 128..2048 tokens, K up to 23 040) split K over 128x128 tiles
         (>= 8 BK64 steps per split, K >= 2048), reduced by igemm_splitk_epilogue."""
+    import os
+    v_small = int(os.environ.get("L2D_IGEMM_V_SMALL", "5"))     # tuning overrides (bench A/B in one gpurun call)
+    v_big = int(os.environ.get("L2D_IGEMM_V_BIG", "5"))
     cdiv = lambda a, b: (a + b - 1) // b
     nk64 = Kp // 64
     big = cdiv(Nout, 128) * cdiv(M, 128) * batch
     small = cdiv(Nout, 64) * cdiv(M, 64) * batch
     if big >= 384:
-        return 1, 1, (4 if big >= 768 else 5)
+        return 1, 1, (4 if big >= 768 else v_big)
     if epi == 1:
-        return 2, 1, 5
+        return 2, 1, v_small
     if nk64 >= 32:
         # long K (3x3 convs below the top level, FF down-projections): 128x128 tiles + split-K beat 64x64 tiles
         # (level-1 conv in the frame: 77 us with 320 small tiles vs 45 us with 80 big tiles x 3 splits)
         s_big = max(1, min(nk64 // 8, round(256 / big), 64))
         if s_big >= 2:
-            return 1, s_big, 5
-    if small >= 256:
-        return 2, 1, 5
-    return 2, 1, 5
+            return 1, s_big, v_big
+    return 2, 1, v_small
 
 
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
