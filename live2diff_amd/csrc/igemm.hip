@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
-    auto swz = [](int r) { return BK == 32 ? ((r >> 1) & 3) : (r & 7); };
+    auto swz = [](int r) { return BK == 32 ? ((r >> 1) & 3) : (BK == 64 ? (r & 7) : (r & 15)); };
 
     // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs): bijective remap so that
     // consecutive tiles -- same token tile, neighbouring weight tiles -- share one XCD's L2
@@ -377,7 +377,7 @@ static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
 }
 
 // pipeline variants (op.i[23]): 0 = BK32 x 4 stages, 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3,
-// 5 = BK64 x 2 (default)
+// 5 = BK64 x 2, 6 = BK128 x 2, 7 = BK128 x 3 (64x64 tile only), 8 = BK64 x 6 (64x64 only), 9 = BK64 x 4 (64x64 only)
 template <int TN, int TM, int MODE>
 static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
     switch (variant) {
@@ -387,6 +387,10 @@ static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
         case 3: launch_v<TN, TM, MODE, 32, 6>(a, batch, s); return L2D_OK;
         case 4: launch_v<TN, TM, MODE, 32, 3>(a, batch, s); return L2D_OK;
         case 5: launch_v<TN, TM, MODE, 64, 2>(a, batch, s); return L2D_OK;
+        case 6: launch_v<TN, TM, MODE, 128, 2>(a, batch, s); return L2D_OK;
+        case 7: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 128, 3>(a, batch, s); return L2D_OK;
+        case 8: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 6>(a, batch, s); return L2D_OK;
+        case 9: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK;
     }
     return L2D_EINVAL;
 }
@@ -419,7 +423,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1)) || (a.stride != 1 && a.stride != 2) ||
         (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
-        variant < 0 || variant > 5 || a.splitk > 64) {
+        variant < 0 || variant > 9 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
         return L2D_EINVAL;
@@ -433,8 +437,11 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         long long big = (long long)((a.Nout + 127) / 128) * ((a.M + 127) / 128) * batch * a.splitk;
         tile = (big >= 384) ? 1 : 2;
     }
-    if (tile == 1) launch_t<128, 128>(a, batch, variant, s);
-    else launch_t<64, 64>(a, batch, variant, s);
+    int lrc = (tile == 1) ? launch_t<128, 128>(a, batch, variant, s) : launch_t<64, 64>(a, batch, variant, s);
+    if (lrc != L2D_OK) {
+        l2d_set_error("igemm(tag %d): pipeline variant %d not available for this tile", op->tag, variant);
+        return lrc;
+    }
     int rc = l2d_check_launch("igemm", op->tag);
     if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;

@@ -274,6 +274,10 @@ class HipStreamingUNet:
             tile, S, variant = ops.igemm_schedule(kw["M"], kw["Nout"], taps * kw["CinP"], batch, kw.get("epi", 0))
             if self.igemm_splitk_off:
                 S = 1
+            if variant in (6, 7) and kw["CinP"] % 128:
+                variant = 1            # BK = 128 rings need K slices of 128
+            if tile == 1 and variant in (7, 8, 9):
+                variant = 5            # deep rings exist for the 64x64 tile only (LDS)
             ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
             op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
             ar.release(ws)
