@@ -114,6 +114,36 @@ def tattn_variant_sweep(unet, reps=5):
     return {f"v{v}": round(min(t), 4) for v, t in out.items()}
 
 
+def op_dims(op, kinds):
+    i = op.i
+    if op.kind == kinds.OP_IGEMM:
+        return (f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} s{i[11]} u{i[12]} e{i[19]} b{max(1, i[20])} "
+                f"S{max(1, i[21])} t{i[22]} v{i[23]}")
+    if op.kind == kinds.OP_FLASH_ATTN:
+        return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
+    if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):
+        return f"N{i[0]} T{i[1]} C{i[2]} L{i[3]}"
+    if op.kind in (kinds.OP_GN_STATS, kinds.OP_GN_APPLY):
+        return f"B{i[0]} T{i[1]} C{i[2] + i[3]} nchunk{i[7]}"
+    if op.kind == kinds.OP_LAYERNORM:
+        return f"rows{i[0]} C{i[1]}"
+    return ""
+
+
+def dump_plan(unet, path):
+    """The stream plan as CSV (index, kernel, dims, flops, bytes, launches): tools/frame_trace.py joins it with a
+    rocprofv3 kernel trace to get the IN-FRAME duration of every launch (cold weights, real neighbours)."""
+    from live2diff_amd import _lib
+    st = unet._plans["stream"]
+    with open(path, "w") as f:
+        f.write("idx,kernel,dims,flops,bytes,dispatches\n")
+        for j in range(len(st.pl)):
+            op = st.pl[j]
+            fl, by = op_work(op, _lib)
+            nd = 0 if op.kind == _lib.OP_COPY else (2 if op.kind == _lib.OP_IGEMM and op.i[21] > 1 else 1)
+            f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{op_dims(op, _lib)},{fl:.0f},{by:.0f},{nd}\n")
+
+
 def per_op_table(unet, path, reps=10):
     """Every launch of the frame timed on its own (HIP events, `reps` back-to-back runs): CSV for tuning."""
     import ctypes
@@ -131,20 +161,7 @@ def per_op_table(unet, path, reps=10):
             pl.time_ms(2)
             us = 1e3 * pl.time_ms(reps)
             fl, by = op_work(op, _lib)
-            i = op.i
-            if op.kind == _lib.OP_IGEMM:
-                dims = f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} s{i[11]} u{i[12]} e{i[19]} b{max(1, i[20])}"
-            elif op.kind == _lib.OP_FLASH_ATTN:
-                dims = f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
-            elif op.kind in (_lib.OP_TATTN_STREAM, _lib.OP_TATTN_WARMUP):
-                dims = f"N{i[0]} T{i[1]} C{i[2]} L{i[3]}"
-            elif op.kind in (_lib.OP_GN_STATS, _lib.OP_GN_APPLY):
-                dims = f"B{i[0]} T{i[1]} C{i[2] + i[3]} nchunk{i[7]}"
-            elif op.kind == _lib.OP_LAYERNORM:
-                dims = f"rows{i[0]} C{i[1]}"
-            else:
-                dims = ""
-            f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{dims},{us:.2f},{fl / us / 1e6 if us else 0:.2f},{by / us / 1e3 if us else 0:.1f}\n")
+            f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{op_dims(op, _lib)},{us:.2f},{fl / us / 1e6 if us else 0:.2f},{by / us / 1e3 if us else 0:.1f}\n")
 
 
 def cpu_baseline(cfg, sd_cpu16, frames=2):
@@ -194,6 +211,7 @@ def main():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--breakdown", type=int, default=1)
     ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
+    ap.add_argument("--dump-plan", type=str, default="", help="write the stream plan (one row per launch) as CSV")
     args = ap.parse_args()
 
     from live2diff_amd import _lib, parallel
@@ -320,6 +338,8 @@ def main():
             result["hbm_copy_gbps_measured"] = f"error: {e}"
     if rank == 0 and args.per_op:
         per_op_table(unet, args.per_op)
+    if rank == 0 and args.dump_plan:
+        dump_plan(unet, args.dump_plan)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames=args.cpu_frames)
     if rank == 0:
