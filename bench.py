@@ -117,8 +117,8 @@ def tattn_variant_sweep(unet, reps=5):
 def op_dims(op, kinds):
     i = op.i
     if op.kind == kinds.OP_IGEMM:
-        return (f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} s{i[11]} u{i[12]} e{i[19]} b{max(1, i[20])} "
-                f"S{max(1, i[21])} t{i[22]} v{i[23]}")
+        return (f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} Kp{i[0] * i[5]} s{i[11]} u{i[12]} e{i[19]} "
+                f"b{max(1, i[20])} S{max(1, i[21])} t{i[22]} v{i[23]} f{int(bool(op.p[9]))}")
     if op.kind == kinds.OP_FLASH_ATTN:
         return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
     if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):

@@ -3,6 +3,7 @@ packers.  Everything here is plumbing: pointers, sizes and strides; the arithmet
 
 Each builder returns `(op, keepalive_tensors)` so that a plan (`_lib.OpList`) can keep the buffers alive.
 """
+import os
 from typing import Optional
 
 import torch
@@ -77,7 +78,7 @@ def zero_page(device) -> torch.Tensor:
     return _ZERO_PAGES[key]
 
 
-def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
+def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, taps: int = 1):
     """(tile, splitk, variant) for an implicit GEMM, from the on-GPU sweep (tools/igemm_sweep.py, profiles/r1b_igemm_sweep.txt).
     tile 1 = 128x128, 2 = 64x64; variant = pipeline shape (igemm.hip launch_p).  These kernels are occupancy /
     latency bound, not DMA-depth bound: what matters is >= ~1.5 waves of blocks over the 256 CUs.
@@ -85,13 +86,21 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
       * otherwise 64x64 tiles if that yields >= 256 blocks;
       * otherwise (low-resolution levels: M = 128..2048 tokens, K up to 23 040) split K over 128x128 tiles
         (>= 8 BK64 steps per split, K >= 2048), reduced by igemm_splitk_epilogue."""
-    import os
+    key = f"{taps},{M},{Nout},{Kp},{epi},{batch}"
+    force = os.environ.get("L2D_IGEMM_FORCE")       # "tile,S,variant": exploration runs of tools/igemm_pick.py
+    if force:
+        t, S, v = (int(x) for x in force.split(","))
+        S = max(1, min(S, Kp // 128))
+        ok = not (v in (6, 7) and (Kp // taps) % 128) and not (t == 1 and v in (7, 8, 9))
+        if ok:
+            return t, S, v
+    elif key in _TUNED:
+        return tuple(_TUNED[key])
     v_small = int(os.environ.get("L2D_IGEMM_V_SMALL", "1"))     # BK64 x 3 stages: in-frame best (85.3 vs 79.9 fps with x2)
     v_big = int(os.environ.get("L2D_IGEMM_V_BIG", "5"))
     cdiv = lambda a, b: (a + b - 1) // b
     nk64 = Kp // 64
     big = cdiv(Nout, 128) * cdiv(M, 128) * batch
-    small = cdiv(Nout, 64) * cdiv(M, 64) * batch
     if big >= 384:
         return 1, 1, (4 if big >= 768 else v_big)
     if epi == 1:
@@ -105,10 +114,25 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0):
     return 2, 1, v_small
 
 
+def _load_tuned():
+    """Per-shape (tile, split-K, pipeline variant) picks measured IN-FRAME on MI355X (tools/igemm_pick.py over
+    rocprofv3 traces of whole frames): the heuristic above is the fallback for shapes the table does not hold."""
+    import json
+    path = os.path.join(os.path.dirname(__file__), "igemm_tuned.json")
+    if os.environ.get("L2D_IGEMM_NO_TABLE") or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)["shapes"]
+
+
+_TUNED = _load_tuned()
+FUSED_SPLITK_MAX = int(os.environ.get("L2D_IGEMM_FUSE_MAX", "8"))   # S <= this: last-arriver reduction inside the GEMM
+
+
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5):
+          variant=5, cnt=None):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
     splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
@@ -124,6 +148,9 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     op.p[6] = _ptr(_h(out)) + out_off * es
     op.p[7] = _ptr(zp)
     op.p[8] = _ptr(ws)
+    op.p[9] = _ptr(cnt)
+    if cnt is not None:
+        assert cnt.dtype == torch.int32
     if bias is not None:
         assert bias.dtype == torch.float32
     if rowbias is not None:
@@ -135,7 +162,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
-    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt)
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):
