@@ -118,7 +118,7 @@ def op_dims(op, kinds):
     i = op.i
     if op.kind == kinds.OP_IGEMM:
         return (f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} Kp{i[0] * i[5]} s{i[11]} u{i[12]} e{i[19]} "
-                f"b{max(1, i[20])} S{max(1, i[21])} t{i[22]} v{i[23]} f{int(bool(op.p[9]))}")
+                f"b{max(1, i[20])} S{max(1, i[21])} t{i[22]} v{i[23]}")
     if op.kind == kinds.OP_FLASH_ATTN:
         return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
     if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):
@@ -140,7 +140,7 @@ def dump_plan(unet, path):
         for j in range(len(st.pl)):
             op = st.pl[j]
             fl, by = op_work(op, _lib)
-            nd = 0 if op.kind == _lib.OP_COPY else (2 if op.kind == _lib.OP_IGEMM and op.i[21] > 1 and not op.p[9] else 1)
+            nd = 0 if op.kind == _lib.OP_COPY else (2 if op.kind == _lib.OP_IGEMM and op.i[21] > 1 else 1)
             f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{op_dims(op, _lib)},{fl:.0f},{by:.0f},{nd}\n")
 
 

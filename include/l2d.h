@@ -54,10 +54,8 @@ enum {
  *   i12 ups(0|1) i13 M i14 Nout i15 ldo i16 ldr i17 ldrb i18 rows_per_bias i19 epi (0 none, 1 GEGLU, 2 SiLU)
  *   i20 batch (grid.z) ; l0..l3 = per-batch element strides of x1, w, out, residual
  *   p7 16-byte zero page (padding source)   p8 split-K workspace [batch][S][M][round_up(Nout,4)] float
- *   p9 split-K tile counters [batch * tiles] int32, zeroed once by the caller (self-resetting), or 0:
- *      with counters the last block of a tile reduces + runs the epilogue inside the GEMM launch (ops that
- *      may run concurrently must not share counters); without, a second launch (igemm_splitk_epilogue) does
- *   i21 splitk (S, 1 = off) i22 tile (0 auto, 1 = 128x128, 2 = 64x64) i23 pipeline variant (igemm.hip launch_p)
+ *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch) i22 tile (0 auto, 1 = 128x128,
+ *   2 = 64x64) i23 pipeline variant (igemm.hip launch_p)
  *
  * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
  *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)

@@ -43,7 +43,6 @@ struct IGemmArgs {
     h16 *out;
     const h16 *zero;   // >= 16 bytes of zeros
     float *ws;         // split-K workspace [S][M][NoutP] fp32
-    int *cnt;          // split-K tile arrival counters (zeroed once, self-resetting) or null: separate epilogue kernel
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
     int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk;
     long long sx1, sw, so, sres;
@@ -295,87 +294,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 
     // ---------------------------------------------------------------- epilogue
     if (gridDim.y > 1) {
-        // split-K: raw fp32 partial tile -> workspace.  Without a counter array the fused epilogue runs in
-        // igemm_splitk_epilogue; with one, the LAST block of each tile to arrive sums the S partials (fixed order
-        // s = 0..S-1, so the result does not depend on which block was last) and runs the epilogue itself.
+        // split-K: raw fp32 partial tile; the fused epilogue runs in igemm_splitk_epilogue
         const int NoutP = (a.Nout + 3) & ~3;
-        const long long slab = (long long)a.M * NoutP;
-        float *wsz = a.ws + (long long)z * gridDim.y * slab;
-        float *wsp = wsz + blockIdx.y * slab;
-        if (!a.cnt) {
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int m = m0 + wm * (TM / 2) + j * 16 + li;
-                if (m >= a.M) continue;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
-                    if (n >= a.Nout) continue;
-                    *reinterpret_cast<f32x4 *>(wsp + (long long)m * NoutP + n) = acc[i][j];
-                }
-            }
-            return;
-        }
-        // Fused reduction.  The 8 XCDs' L2s are not coherent with each other inside a kernel and a device-scope
-        // fence costs a whole-L2 write-back + invalidate per block (measured: 84 -> 71 frames/s), so the partials
-        // travel with device-coherent accesses instead: sc1 stores write through to memory, sc1 loads miss L2
-        // (the encodings LLVM uses for agent-scope monotonic atomics on gfx942/gfx950), ordered by vmcnt(0).
+        float *wsp = a.ws + ((long long)z * gridDim.y + blockIdx.y) * a.M * NoutP;
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int m = m0 + wm * (TM / 2) + j * 16 + li;
+            if (m >= a.M) continue;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
-                if (m < a.M && n < a.Nout)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(wsp + (long long)m * NoutP + n), "v"(acc[i][j]) : "memory");
+                if (n >= a.Nout) continue;
+                *reinterpret_cast<f32x4 *>(wsp + (long long)m * NoutP + n) = acc[i][j];
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials are acknowledged by memory
-        __syncthreads();
-        int *flag = reinterpret_cast<int *>(smem);
-        if (tid == 0) {
-            int *c = a.cnt + z * gridDim.x + blockIdx.x;
-            const int last = (atomicAdd(c, 1) == (int)gridDim.y - 1);
-            if (last) atomicExch(c, 0);    // self-resetting: the next launch finds zeros
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        // last arriver: sum the S partials in the fixed order s = 0..S-1 (own partial included, re-read), so the
-        // result does not depend on which block was last
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int CHUNK = (NI * MI <= 4) ? 4 : 1;           // splits loaded per round trip (<= 16 loads in flight)
-        for (int s0 = 0; s0 < (int)gridDim.y; s0 += CHUNK) {
-            f32x4 part[CHUNK][NI][MI];
-#pragma unroll
-            for (int c = 0; c < CHUNK; ++c)
-#pragma unroll
-                for (int j = 0; j < MI; ++j) {
-                    const int m = m0 + wm * (TM / 2) + j * 16 + li;
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
-                        // unconditional load (no control flow between the load and the wait): lanes / splits
-                        // that are out of range read a valid dummy address and are masked after the wait
-                        const bool ok = s0 + c < (int)gridDim.y && m < a.M && n < a.Nout;
-                        const float *src = ok ? wsz + (s0 + c) * slab + (long long)m * NoutP + n : wsz;
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[c][i][j]) : "v"(src) : "memory");
-                    }
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int c = 0; c < CHUNK; ++c)
-#pragma unroll
-                for (int j = 0; j < MI; ++j)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        asm volatile("" : "+v"(part[c][i][j]));        // value is defined only after the wait above
-                        if (s0 + c < (int)gridDim.y) acc[i][j] += part[c][i][j];
-                    }
-        }
+        return;
     }
     if (a.epi == 1) {
         // GEGLU: fragment pairs (2p, 2p+1) hold value / gate of the same output columns
@@ -473,7 +406,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     IGemmArgs a;
     a.x1 = (const h16 *)op->p[0]; a.x2 = (const h16 *)op->p[1]; a.w = (const h16 *)op->p[2];
     a.bias = (const float *)op->p[3]; a.rowbias = (const float *)op->p[4];
-    a.res = (const h16 *)op->p[5]; a.out = (h16 *)op->p[6]; a.zero = (const h16 *)op->p[7]; a.ws = (float *)op->p[8]; a.cnt = (int *)op->p[9];
+    a.res = (const h16 *)op->p[5]; a.out = (h16 *)op->p[6]; a.zero = (const h16 *)op->p[7]; a.ws = (float *)op->p[8];
     a.taps = op->i[0]; a.C1 = op->i[1]; a.C2 = op->i[2]; a.ldx1 = op->i[3]; a.ldx2 = op->i[4];
     a.CinP = op->i[5]; a.B = op->i[6]; a.Hin = op->i[7]; a.Win = op->i[8]; a.Hout = op->i[9];
     a.Wout = op->i[10]; a.stride = op->i[11]; a.ups = op->i[12]; a.M = op->i[13]; a.Nout = op->i[14];
@@ -488,7 +421,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         a.M <= 0 || a.Nout <= 0 || (a.C1 % 8) || (a.C2 % 8) || (a.C2 > 0 && !a.x2) || a.C1 + a.C2 > a.CinP ||
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
-        (a.epi == 1 && (!a.bias || (a.Nout % 32) || (a.splitk != 1 && !a.cnt))) || (a.stride != 1 && a.stride != 2) ||
+        (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1)) || (a.stride != 1 && a.stride != 2) ||
         (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 9 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
@@ -510,7 +443,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         return lrc;
     }
     int rc = l2d_check_launch("igemm", op->tag);
-    if (rc != L2D_OK || a.splitk == 1 || a.cnt) return rc;
+    if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
     long long total = (long long)a.M * (NoutP / 4);
     hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);

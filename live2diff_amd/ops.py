@@ -126,13 +126,12 @@ def _load_tuned():
 
 
 _TUNED = _load_tuned()
-FUSED_SPLITK_MAX = int(os.environ.get("L2D_IGEMM_FUSE_MAX", "8"))   # S <= this: last-arriver reduction inside the GEMM
 
 
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5, cnt=None):
+          variant=5):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
     splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
@@ -148,9 +147,6 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     op.p[6] = _ptr(_h(out)) + out_off * es
     op.p[7] = _ptr(zp)
     op.p[8] = _ptr(ws)
-    op.p[9] = _ptr(cnt)
-    if cnt is not None:
-        assert cnt.dtype == torch.int32
     if bias is not None:
         assert bias.dtype == torch.float32
     if rowbias is not None:
@@ -162,7 +158,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
-    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):

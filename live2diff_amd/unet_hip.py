@@ -279,19 +279,14 @@ class HipStreamingUNet:
                 variant = 1            # BK = 128 rings need K slices of 128
             if tile == 1 and variant in (7, 8, 9):
                 variant = 5            # deep rings exist for the 64x64 tile only (LDS)
-            tsz = 128 if tile == 1 else 64
-            ntiles = batch * ((kw["M"] + tsz - 1) // tsz) * ((kw["Nout"] + tsz - 1) // tsz)
-            fused = 1 < S <= ops.FUSED_SPLITK_MAX and ntiles <= st.splitk_cnt.numel()
-            if epi == 1 and not fused:
-                S = 1                  # GEGLU needs value and gate in one block's registers: fused reduction only
+            if epi == 1:
+                S = 1                  # GEGLU pairs value and gate in one block's registers: no split-K
             ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
-            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant,
-                               cnt=(st.splitk_cnt if fused else None), **kw))
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
             ar.release(ws)
             return op
 
         # ---- static inputs
-        st.splitk_cnt = torch.zeros(1 << 16, dtype=torch.int32, device=dev)   # igemm split-K tile arrival counters
         st.in_sample = torch.zeros(B, cfg.in_channels, h * w, dtype=torch.float16, device=dev)
         st.in_depth = torch.zeros_like(st.in_sample)
         st.in_t = torch.zeros(Bt, dtype=torch.int64, device=dev)
