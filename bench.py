@@ -89,7 +89,7 @@ def per_kernel_breakdown(unet, reps=5):
     return rows
 
 
-def tattn_variant_sweep(unet, reps=5):
+def tattn_variant_sweep(unet, reps=5, variants=(1, 10, 13)):
     """A/B of the streaming temporal-attention kernel variants on this frame's 40 launches (same process,
     interleaved): ms per frame for variant 1 (register resident), 2 (chunked CH=8), 3 (chunked CH=4)."""
     import ctypes
@@ -98,7 +98,7 @@ def tattn_variant_sweep(unet, reps=5):
     st = unet._plans["stream"]
     src = [st.pl[j] for j in range(len(st.pl)) if st.pl[j].kind == _lib.OP_TATTN_STREAM]
     lists = {}
-    for v in (1, 6, 7):
+    for v in variants:
         pl = _lib.OpList()
         for op in src:
             c = _lib.L2dOp()

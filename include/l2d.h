@@ -73,7 +73,9 @@ enum {
  *                (reference stream_motion_module.py:99-213)
  *   p0 qkv [N*T][3C] half p1 cache [N,2,T,L,C] half (in-place) p2 q_pe p3 k_pe p4 v_pe [maxlen][C] half
  *   p5 pe_idx [N][L] int64 p6 update_idx [N] int64 p7 bias [N][L] half p8 out [N*T][C] half
- *   i0 N i1 T i2 C i3 L i4 H i5 variant (0 auto; 1 register-resident, 2/3 chunked CH=8/4: tuning knob)
+ *   p9 16-byte zero page (DMA source of masked slots; required by the ring kernel, may be 0 otherwise)
+ *   i0 N i1 T i2 C i3 L i4 H i5 variant (0 auto: LDS-DMA ring kernel for C in {320,640,1280}, L in {12,16},
+ *   T % 8 == 0, else register-resident / chunked; 1 register-resident, 2/3 chunked CH=8/4, 13 ring: tuning knob)
  *
  * L2D_OP_TATTN_WARMUP  bidirectional warm-up temporal attention + cache fill
  *                (reference motion_module.py:469-530)

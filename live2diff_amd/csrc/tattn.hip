@@ -16,17 +16,7 @@
 //     through LDS (padded rows, conflict-free float4 writes; same-address broadcast reads).
 // Block = PB pixels x TP threads (TP = C/8), PB chosen so that the block is 256..320 threads.
 // Masked slots (bias == -inf) are never read: their softmax weight is exactly 0.
-#include "common.h"
-
-struct TAttnArgs {
-    const h16 *qkv;
-    h16 *cache;
-    const h16 *q_pe, *k_pe, *v_pe;
-    const long long *pe_idx, *update_idx;
-    const h16 *bias;
-    h16 *out;
-    int N, T, C, L, H, variant;
-};
+#include "tattn.h"
 
 __device__ __forceinline__ float dot8(h16x8 a, h16x8 b) {
     float s = 0.f;
@@ -370,6 +360,32 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_chunked_kernel(TAttnArgs 
     }
 }
 
+// Streaming probes with the stream kernel's exact geometry (variants 10/11/12, analysis only -- the output is NOT
+// attention): MODE 0 = sum of all K and V rows, 1 = K rows only, 2 = K + V rows + the gathered PE rows.  They
+// bound what this access pattern can reach with no dependent index loads, no LDS exchange and no softmax.
+template <int TP, int PB, int L, int MODE>
+__global__ __launch_bounds__(TP *PB) void tattn_probe_kernel(TAttnArgs a) {
+    const int tid = threadIdx.x;
+    const int p = tid / TP, cc = tid - p * TP;
+    const long long NT = (long long)a.N * a.T;
+    const long long pix = (long long)blockIdx.x * PB + p;
+    if (pix >= NT) return;
+    const int n = (int)(pix / a.T);
+    const long long t = pix - (long long)n * a.T;
+    const int C = a.C;
+    const h16 *kc = a.cache + (((long long)n * 2 + 0) * a.T + t) * L * C + cc * 8;
+    const h16 *vc = a.cache + (((long long)n * 2 + 1) * a.T + t) * L * C + cc * 8;
+    const long long *pei = a.pe_idx + (long long)n * L;
+    h16x8 acc = l2d_zero8();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        acc = acc + l2d_ld8(kc + (long long)l * C);
+        if (MODE != 1) acc = acc + l2d_ld8(vc + (long long)l * C);
+        if (MODE == 2) acc = acc + l2d_ld8(a.k_pe + pei[l] * C + cc * 8) + l2d_ld8(a.v_pe + pei[l] * C + cc * 8);
+    }
+    l2d_st8(a.out + pix * C + cc * 8, acc);
+}
+
 template <int TP, int PB, int L>
 static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
     long long NT = (long long)a.N * a.T;
@@ -385,6 +401,12 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), true, 1>), dim3(nb), dim3(TP * PB), lds, s, a);
     else if (v == 9 && L <= 16)
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), true, 2>), dim3(nb), dim3(TP * PB), lds, s, a);
+    else if (v >= 10 && v <= 12 && L <= 16) {
+        constexpr int LL = (L <= 16 ? L : 16);
+        if (v == 10) hipLaunchKernelGGL((tattn_probe_kernel<TP, PB, LL, 0>), dim3(nb), dim3(TP * PB), 0, s, a);
+        if (v == 11) hipLaunchKernelGGL((tattn_probe_kernel<TP, PB, LL, 1>), dim3(nb), dim3(TP * PB), 0, s, a);
+        if (v == 12) hipLaunchKernelGGL((tattn_probe_kernel<TP, PB, LL, 2>), dim3(nb), dim3(TP * PB), 0, s, a);
+    }
     else if (v == 7 && L <= 16)   // PE rows staged in LDS
         hipLaunchKernelGGL((tattn_stream_lds_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB),
                            lds + (size_t)2 * L * TP * 8 * sizeof(h16), s, a);
@@ -441,6 +463,16 @@ int l2d_launch_tattn_stream(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
+    // LDS-DMA ring kernel (tattn_ring.hip): the default wherever it applies (1.00 vs 1.33 ms per cfg-2 frame)
+    if (a.variant == 13 || (a.variant == 0 && l2d_tattn_ring_ok(a, op->p[9]))) {
+        if (!l2d_tattn_ring_ok(a, op->p[9])) {
+            l2d_set_error("tattn_stream(tag %d): ring variant needs C in {320,640,1280}, L in {12,16}, T %% 8 == 0, p9 = zero page", op->tag);
+            return L2D_EINVAL;
+        }
+        rc = l2d_launch_tattn_ring(a, op->p[9], s);
+        if (rc) return rc;
+        return l2d_check_launch("tattn_stream_ring", op->tag);
+    }
     switch (a.C) {
         case 64: rc = launch_stream_l<8, 32>(a, s); break;
         case 128: rc = launch_stream_l<16, 16>(a, s); break;

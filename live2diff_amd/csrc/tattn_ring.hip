@@ -1,0 +1,263 @@
+// Streaming temporal attention, LDS-DMA ring kernel (SD widths C = 320 / 640 / 1280, window L = 12 / 16).
+// Same math and rounding points as tattn_stream_kernel (tattn.hip; reference stream_motion_module.py:99-213).
+//
+// Why: the register-resident kernel issues all 2L loads of a pixel, waits, then computes; per cfg-2 frame that is
+// 0.63 ms of streaming (probe, 4.85 TB/s) PLUS 0.49 ms of compute = 1.33 ms measured -- nothing overlaps, because a
+// launch is only ~2 rounds of blocks and co-resident blocks run in lockstep.  Here the K / V slabs stream
+// HBM -> LDS through a ring of `global_load_lds` stages (no VGPRs held by loads in flight), so the rows of the next
+// stages / the next pixel group land while the current stage's dot products, the score exchange and the softmax
+// run.
+//
+// Mapping.  Work item = (pixel t, 320-channel chunk): TP = 40 threads x 8 channels, so every width has the same
+// geometry.  A block owns ONE (batch row n, chunk) and `gpb` consecutive groups of PB = 8 pixels (320 threads:
+// thread = (p, cc)), so update_idx / bias / pe_idx and the gathered positional-encoding rows (2 x L x 640 B, staged
+// once in LDS) are block constants.  A stage is R = 4 cache rows of the group's K (then V): 4 rows x 8 pixels x
+// 640 B = 20 KB, laid out [r][p][cc] = [r][tid]: DMA instruction j of a stage moves row l0 + j for all 320 threads,
+// thread tid fetching the 16 bytes it will consume itself.  So the row, its source (cache / new row / masked) and
+// the source base address are wave-uniform (SALU), the per-thread part of the address is one constant 32-bit
+// offset, and both the DMA's LDS image and the consumer's ds_read_b128 are lane-linear (conflict free).
+// Per group: L/4 K stages -> score exchange over the d/8 threads of a head + softmax -> L/4 V stages.
+// Masked slots (bias = -inf) are never fetched from the cache: their DMA reads the zero page (every thread still
+// issues exactly LPS loads per stage, which keeps the counted vmcnt waits valid) and their softmax weight is
+// exactly 0.  The new row (slot update_idx[n]) is DMA'd from the qkv projection buffer instead of the cache and
+// written to the cache from LDS by its consumer.
+//
+// VMEM discipline: everything the inner loop needs comes through the ring or LDS.  A register spill or an
+// ordinary global load whose value is needed soon would sit in the same in-order VMEM queue BEHIND the ring's
+// outstanding stages and drain the pipeline, so the only ordinary loads are the next group's q row (issued L/8
+// stages before use) and the stores (never waited on).  The loop is instruction-issue bound on the SIMD that hosts
+// two of the block's five waves, hence v_dot2_f32_f16 / v_fma_mix_f32 and uniform control flow throughout.
+#include "tattn.h"
+
+#define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
+#define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// dot product on v_dot2_f32_f16: two exact fp16 products + fp32 accumulate per instruction
+__device__ __forceinline__ float ring_dot8(h16x8 a, h16x8 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) s = __builtin_amdgcn_fdot2((h16x2){a[e], a[e + 1]}, (h16x2){b[e], b[e + 1]}, s, false);
+    return s;
+}
+
+// o[0..7] += p * float(v[0..7]) on v_fma_mix_f32 (fp16 operand converted inside the FMA: no separate v_cvt)
+__device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(o[2 * e]) : "v"(w[e]), "v"(p));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(o[2 * e + 1]) : "v"(w[e]), "v"(p));
+    }
+}
+
+template <int HG, int L>   // HG = threads per head (d / 8): 5, 10, 20
+__global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
+    constexpr int TP = 40, PB = 8, R = 4, NSTG = 2 * L / R, NS = 5, LPS = R;
+    constexpr int STAGE_H = R * PB * TP * 8;       // halfs per stage (20 KB)
+    constexpr int LP = L + 4;
+    // LDS: ring [NS][20 KB] | score rows [320][LP] f32 | bias of row n [L] f32 | k_pe rows [L][40][8] | v_pe rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+    h16 *ring = reinterpret_cast<h16 *>(ring_raw);
+    float *sp = reinterpret_cast<float *>(ring_raw + (size_t)NS * STAGE_H * sizeof(h16));
+    float *blds = sp + 320 * LP;
+    h16 *kpl = reinterpret_cast<h16 *>(blds + L);
+    h16 *vpl = kpl + L * 320;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = tid / TP, cc = tid - p * TP;
+    const int C = a.C, CH = C / 320;
+    // block -> (n, chunk, first group); the divisions run on the VALU, pin the results to SGPRs
+    const int bpu = (groups_per_unit + gpb - 1) / gpb;
+    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x / bpu);
+    const int n = __builtin_amdgcn_readfirstlane(unit / CH);
+    const int chunk = unit - n * CH;
+    const int g0 = (blockIdx.x - unit * bpu) * gpb;
+    const int ng = min(gpb, groups_per_unit - g0);
+    const long long slab = (long long)a.T * L * C;
+    // uniform bases (SGPRs) of the block's first pixel; per-thread parts are the 32-bit offsets below
+    h16 *kbase = a.cache + (long long)n * 2 * slab + (long long)g0 * PB * L * C + chunk * 320;
+    h16 *vbase = kbase + slab;
+    const h16 *qkv_b = a.qkv + ((long long)n * a.T + g0 * PB) * 3 * C + chunk * 320;
+    h16 *out_b = a.out + ((long long)n * a.T + g0 * PB) * C + chunk * 320;
+    const unsigned coff = (unsigned)(p * L * C + cc * 8);       // cache: + l * C, + group * PB*L*C
+    const unsigned qoff = (unsigned)(p * 3 * C + cc * 8);       // qkv:   + C (k) / 2C (v), + group * PB*3C
+    const unsigned ooff = (unsigned)(p * C + cc * 8);           // out:   + group * PB*C
+
+    // ---- block constants of batch row n
+    const int u = __builtin_amdgcn_readfirstlane((int)a.update_idx[n]);
+    const long long *pei = a.pe_idx + (long long)n * L;
+    const h16 *bi = a.bias + (long long)n * L;
+    unsigned live = 0;                              // bit l: slot l is fetched from the cache
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        if ((float)bi[l] > -1e30f && l != u) live |= 1u << l;
+    live = __builtin_amdgcn_readfirstlane(live);
+    if (tid < L) blds[tid] = (float)bi[tid];        // visible after the first stage barrier
+    // gathered PE rows of this chunk -> LDS by DMA (older than every ring load: landed before the first stage is
+    // consumed, visible to the block after that stage's barrier).  L * 40 items of 16 B per table.
+#pragma unroll
+    for (int f0 = 0; f0 < L * TP; f0 += 320) {
+        const int f = f0 + tid;
+        if (f < L * TP) {
+            const int l = f / TP, c = f - l * TP;
+            const long long po = pei[l] * C + chunk * 320 + c * 8;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.k_pe + po), L2D_LPTR(kpl + (f0 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.v_pe + po), L2D_LPTR(vpl + (f0 + wave * 64) * 8), 16, 0, 0);
+        }
+    }
+    const h16x8 qpe = l2d_ld8(a.q_pe + pei[u] * C + chunk * 320 + cc * 8);
+
+    // ---- DMA side
+    const int total = ng * NSTG;
+    int it_issue = 0, is_s = 0, is_slot = 0, is_g = 0;
+    auto issue = [&]() {
+        const bool isv = is_s >= NSTG / 2;
+        const int l0 = (isv ? is_s - NSTG / 2 : is_s) * R;
+        const h16 *cb = (isv ? vbase : kbase) + (long long)is_g * (PB * L * C);
+        const h16 *qb = qkv_b + (long long)is_g * (PB * 3 * C) + (isv ? 2 * C : C);
+        h16 *dst = ring + is_slot * STAGE_H + wave * 512;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int l = l0 + j;                                // uniform
+            const h16 *src = zero;
+            if ((live >> l) & 1) src = cb + l * C + coff;
+            else if (l == u) src = qb + qoff;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst + j * 320 * 8), 16, 0, 0);
+        }
+        ++it_issue;
+        if (++is_s == NSTG) { is_s = 0; ++is_g; }
+        is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (it_issue < total) issue();
+
+    const float scale = rsqrtf((float)(C / a.H));
+    const int gs = p * TP + (cc / HG) * HG;
+    float *row = sp + tid * LP;
+    const h16 *kpt = kpl + cc * 8, *vpt = vpl + cc * 8;           // + l * 320
+    int it = 0, cs_slot = 0;
+    h16x8 qn = l2d_zero8();
+    for (int gi = 0; gi < ng; ++gi) {
+        h16x8 q8 = qn;
+        if (gi == 0) q8 = l2d_ld8(qkv_b + qoff);
+        q8 = q8 + qpe;                                           // fp16 add, as the reference (:139)
+        h16 *ku = kbase + (long long)gi * (PB * L * C) + u * C;  // uniform: slot u of the group's first pixel
+        float sc[L];
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTG; ++s) {
+            // stage `it` has landed when at most NS-2 younger stages are outstanding (in-order return; other VMEM ops
+            // in flight only make this wait longer, never shorter)
+            if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (it_issue < total) issue();                       // refills the slot every wave finished one stage ago
+            const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
+            if (s < NSTG / 2) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int l = s * R + r;
+                    h16x8 kk = l2d_ld8(st + r * 320 * 8);        // masked slots hold zeros
+                    if (l == u) l2d_st8(ku + coff, kk);          // cache keeps the pre-PE projections (:117-119)
+                    kk = kk + l2d_ld8(kpt + l * 320);            // fp16 rounding of K+pe as in the reference (:140)
+                    sc[l] = ring_dot8(q8, kk);
+                }
+                if (s == NSTG / 2 - 1) {
+                    // per-head score reduction over the HG threads of a head, then the 1 x L softmax
+#pragma unroll
+                    for (int l = 0; l < L; l += 4) *reinterpret_cast<f32x4 *>(row + l) = (f32x4){sc[l], sc[l + 1], sc[l + 2], sc[l + 3]};
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+#pragma unroll
+                    for (int l = 0; l < L; ++l) sc[l] = 0.f;
+#pragma unroll 2
+                    for (int j = 0; j < HG; ++j) {
+                        const float *rr = sp + (gs + j) * LP;
+#pragma unroll
+                        for (int l = 0; l < L; l += 4) {
+                            f32x4 x = *reinterpret_cast<const f32x4 *>(rr + l);
+                            sc[l] += x[0]; sc[l + 1] += x[1]; sc[l + 2] += x[2]; sc[l + 3] += x[3];
+                        }
+                    }
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int l = 0; l < L; l += 4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(blds + l);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { sc[l + e] = sc[l + e] * scale + b4[e]; mx = fmaxf(mx, sc[l + e]); }
+                    }
+                    float den = 0.f;
+#pragma unroll
+                    for (int l = 0; l < L; ++l) { sc[l] = __expf(sc[l] - mx); den += sc[l]; }
+                    const float inv = 1.0f / den;
+#pragma unroll
+                    for (int l = 0; l < L; ++l) sc[l] *= inv;
+                }
+            } else {
+                if (s == NSTG / 2 && gi + 1 < ng)                // next group's q row: in flight for NSTG/2 stages
+                    qn = l2d_ld8(qkv_b + (long long)(gi + 1) * (PB * 3 * C) + qoff);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int l = (s - NSTG / 2) * R + r;
+                    h16x8 vv = l2d_ld8(st + r * 320 * 8);
+                    if (l == u) l2d_st8(ku + slab + coff, vv);
+                    vv = vv + l2d_ld8(vpt + l * 320);            // (:141)
+                    ring_axpy8(o, sc[l], vv);
+                }
+            }
+            ++it;
+            cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
+        }
+        h16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+        l2d_st8(out_b + (long long)gi * (PB * C) + ooff, ov);
+    }
+}
+
+template <int L, int HG>
+static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
+    constexpr size_t LDS = (size_t)5 * 8 * 4 * 40 * 16 + (size_t)(320 * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
+    static bool attr_done = false;
+    if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel
+        (void)hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr_done = true;
+    }
+    const int CH = a.C / 320;
+    const int groups_per_unit = a.T / 8;
+    const int total = a.N * CH * groups_per_unit;
+    const int gpb = (total + cus - 1) / cus;       // one LDS-filling block per CU, persistent over gpb groups
+    const int bpu = (groups_per_unit + gpb - 1) / gpb;
+    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L>), dim3(a.N * CH * bpu), dim3(320), LDS, s, a, zero, gpb, groups_per_unit);
+}
+
+bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
+    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12) && (a.T % 8 == 0) && a.H == 8;
+}
+
+int l2d_launch_tattn_ring(const TAttnArgs &a, const void *zero_page, hipStream_t s) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return L2D_ELAUNCH;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const h16 *zero = (const h16 *)zero_page;
+    if (a.L == 16) {
+        if (a.C == 320) launch_ring<16, 5>(a, zero, cus, s);
+        else if (a.C == 640) launch_ring<16, 10>(a, zero, cus, s);
+        else launch_ring<16, 20>(a, zero, cus, s);
+    } else {
+        if (a.C == 320) launch_ring<12, 5>(a, zero, cus, s);
+        else if (a.C == 640) launch_ring<12, 10>(a, zero, cus, s);
+        else launch_ring<12, 20>(a, zero, cus, s);
+    }
+    return L2D_OK;
+}

@@ -210,11 +210,12 @@ def tattn_stream(qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out, *,
     assert pe_idx.dtype == torch.int64 and update_idx.dtype == torch.int64 and bias.dtype == torch.float16
     op = L2dOp()
     op.kind = _lib.OP_TATTN_STREAM
-    for j, t in enumerate([qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out]):
+    zp = zero_page(qkv.device)                      # DMA source of masked slots (ring kernel)
+    for j, t in enumerate([qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out, zp]):
         op.p[j] = _ptr(t)
     for j, v in enumerate([N, T, C, L, H, variant]):
         op.i[j] = int(v)
-    return op, (qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out)
+    return op, (qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out, zp)
 
 
 def tattn_warmup(qkv, cache_row, q_pe, k_pe, v_pe, out, *, F, T, C, L, H):

@@ -283,7 +283,10 @@ def _tattn_case(C, T, Lw, S, N, seed, ramp=True):
                                                 (320, 100, 16, 8, 2, 3), (640, 64, 16, 8, 2, 0), (1280, 16, 16, 8, 2, 0),
                                                 (1280, 64, 40, 8, 2, 0), (256, 37, 24, 8, 3, 0),
                                                 (320, 256, 16, 8, 2, 7), (640, 64, 16, 8, 2, 7), (1280, 16, 16, 8, 2, 7),
-                                                (64, 50, 12, 4, 1, 7), (256, 37, 16, 8, 3, 7), (320, 100, 16, 8, 2, 6)])
+                                                (64, 50, 12, 4, 1, 7), (256, 37, 16, 8, 3, 7), (320, 100, 16, 8, 2, 6),
+                                                (320, 256, 16, 8, 2, 13), (640, 64, 16, 8, 2, 13), (1280, 16, 16, 8, 2, 13),
+                                                (320, 1024, 16, 8, 3, 13), (640, 104, 12, 4, 2, 13), (1280, 8, 12, 4, 1, 13),
+                                                (320, 4096, 16, 8, 2, 13), (1280, 64, 16, 8, 2, 13), (640, 1024, 16, 8, 2, 13)])
 def test_tattn_stream(L, C, T, Lw, S, N, variant):
     from live2diff_amd.config import tiny_config
     from oracle import unet_ref as O
