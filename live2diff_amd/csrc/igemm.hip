@@ -44,7 +44,7 @@ struct IGemmArgs {
     const h16 *zero;   // >= 16 bytes of zeros
     float *ws;         // split-K workspace [S][M][NoutP] fp32
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
-    int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk;
+    int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order;
     long long sx1, sw, so, sres;
 };
 
@@ -111,9 +111,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // Each XCD runs a contiguous range of wgid.  order 0: token-tile major (an XCD owns a band of token rows and walks
+    // all weight tiles: every XCD's L2 pulls the whole weight matrix -- right when activations dominate); order 1:
+    // weight-tile major (an XCD owns a band of output channels: the weights enter ONE L2, the small activation
+    // matrix enters all eight -- right for the low-resolution levels, where weights are 10-100x the activations).
     const int ntn = (a.Nout + TN - 1) / TN;
-    const int tile_n = wgid % ntn;
-    const int tile_m = wgid / ntn;
+    int tile_n, tile_m;
+    if (a.order) {
+        const int ntm = nwg / ntn;
+        tile_m = wgid % ntm;
+        tile_n = wgid / ntm;
+    } else {
+        tile_n = wgid % ntn;
+        tile_m = wgid / ntn;
+    }
     const int n0 = tile_n * TN, m0 = tile_m * TM;
     const long long z = blockIdx.z;
     const h16 *x1 = a.x1 + z * a.sx1;
@@ -413,7 +424,8 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.ldo = op->i[15]; a.ldr = op->i[16]; a.ldrb = op->i[17]; a.rows_per_bias = op->i[18]; a.epi = op->i[19];
     int batch = op->i[20] > 0 ? op->i[20] : 1;
     a.splitk = op->i[21] > 0 ? op->i[21] : 1;
-    int tile = op->i[22];      // 0 auto, 1 = 128x128, 2 = 64x64
+    int tile = op->i[22] & 15; // 0 auto, 1 = 128x128, 2 = 64x64
+    a.order = (op->i[22] >> 4) & 1;   // XCD tile order: 0 token-tile major, 1 weight-tile major
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.Kp = a.taps * a.CinP;

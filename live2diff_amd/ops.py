@@ -131,7 +131,7 @@ _TUNED = _load_tuned()
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5):
+          variant=5, order=0):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
     splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
@@ -154,7 +154,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     if splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
-            rows_per_bias, epi, batch, splitk, tile, variant]
+            rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order), variant]
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)

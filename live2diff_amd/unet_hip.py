@@ -22,6 +22,7 @@ host-to-static-buffer input copies).
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
+import os
 import torch
 
 from . import _lib, ops
@@ -282,7 +283,11 @@ class HipStreamingUNet:
             if epi == 1:
                 S = 1                  # GEGLU pairs value and gate in one block's registers: no split-K
             ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
-            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
+            # XCD tile order: weight-tile major when the weight matrix outweighs the activations (L2 fills, see igemm.hip)
+            wbytes = kw["Nout"] * taps * kw["CinP"]
+            xbytes = kw["M"] * (kw["C1"] + kw.get("C2", 0))
+            order = {"0": 0, "1": 1}.get(os.environ.get("L2D_IGEMM_ORDER", ""), int(wbytes > xbytes))
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order, **kw))
             ar.release(ws)
             return op
 
