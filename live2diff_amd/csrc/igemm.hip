@@ -43,13 +43,24 @@ struct IGemmArgs {
     h16 *out;
     const h16 *zero;   // >= 16 bytes of zeros
     float *ws;         // split-K workspace [S][M][NoutP] fp32
+    // LayerNorm fold (consumer): x is the RAW pre-norm tensor, the weights carry gamma, and the epilogue turns
+    //   acc = sum_k x[m][k] W'[n][k]  into  rstd[m] * (acc - mean[m] * colsum[n]) (+ bias' ...), with
+    // mean / rstd of row m from `ln_P` partial (sum, sumsq) pairs written by the epilogue of the launch that
+    // produced x (`stat_out`): [M][P][2] floats, P = 2 * (Nout tiles) from the tile kernel, 1 from the split-K
+    // row epilogue.
+    const float *ln_stat, *ln_colsum;
+    float *stat_out;
+    float ln_eps;
+    int ln_P;
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
     int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order;
     long long sx1, sw, so, sres;
 };
 
-// fused epilogue for 4 consecutive output channels n..n+3 of token m
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v) {
+// fused epilogue for 4 consecutive output channels n..n+3 of token m; s1 / s2 accumulate the sum and the sum of
+// squares of the fp16 values actually stored (the row statistics a LayerNorm-folded consumer will read)
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v,
+                                               float &s1, float &s2) {
     const float *rb = a.rowbias ? a.rowbias + (long long)(m / a.rows_per_bias) * a.ldrb : nullptr;
     if (n + 4 > a.Nout) {
         // ragged last channel group (Nout % 4 != 0, e.g. the swapped V^T GEMM with an odd token count)
@@ -61,7 +72,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
             if (rb) y += rb[n + r];
             if (a.epi == 2) y = l2d_silu(y);
             if (resp) y += (float)resp[(long long)m * a.ldr + n + r];
-            outp[(long long)m * a.ldo + n + r] = (h16)y;
+            const h16 yh = (h16)y;
+            outp[(long long)m * a.ldo + n + r] = yh;
+            s1 += (float)yh; s2 += (float)yh * (float)yh;
         }
         return;
     }
@@ -78,8 +91,23 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
     }
     h16x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+    for (int r = 0; r < 4; ++r) {
+        o[r] = (h16)v[r];
+        s1 += (float)o[r]; s2 += (float)o[r] * (float)o[r];
+    }
     *reinterpret_cast<h16x4 *>(outp + (long long)m * a.ldo + n) = o;
+}
+
+// LayerNorm fold: acc -> rstd * acc - (rstd * mean) * colsum for 4 consecutive channels of one token
+__device__ __forceinline__ f32x4 igemm_ln_fold(const IGemmArgs &a, int n, f32x4 v, float rstd, float rmean) {
+    if (n + 4 > a.Nout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < a.Nout) v[r] = rstd * v[r] - rmean * a.ln_colsum[n + r];
+        return v;
+    }
+    const f32x4 cs = *reinterpret_cast<const f32x4 *>(a.ln_colsum + n);
+    return rstd * v - rmean * cs;
 }
 
 // MODE 0: linear / 1x1 (taps = 1);  MODE 1: 3x3, single input, no upsample (fast gather);  MODE 2: 3x3 generic
@@ -288,6 +316,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (kb + s < ke) issue();
+    // LayerNorm fold: (rstd, rstd * mean) of this block's token rows -> LDS behind the ring.  Issued after the ring's
+    // first stages (the wait for these loads also covers them: in-order VMEM queue), read only in the epilogue.
+    float *lnm = reinterpret_cast<float *>(smem + NS * STAGE);      // [TM][2]
+    if (a.ln_stat && gridDim.y == 1 && tid < TM) {
+        const int m = m0 + tid;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < a.M) {
+            const float *sp = a.ln_stat + (long long)m * a.ln_P * 2;
+            for (int q = 0; q < a.ln_P; ++q) { s1 += sp[2 * q]; s2 += sp[2 * q + 1]; }
+        }
+        const float inv = 1.0f / (float)Ctot;
+        const float mean = s1 * inv;
+        const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+        lnm[2 * tid] = rstd;
+        lnm[2 * tid + 1] = rstd * mean;
+    }
     // steady state: stage kt has landed when at most (NS-2) younger stages are still outstanding
     int kt = kb;
     for (; kt + (NS - 1) < ke; ++kt) {
@@ -335,6 +379,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
                 const int no = (n0 + wn * (TN / 2)) / 2 + p * 16 + lg * 4;      // output column
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + nv);
                 const f32x4 bg = *reinterpret_cast<const f32x4 *>(a.bias + ng);
+                if (a.ln_stat) {
+                    const float rstd = lnm[2 * (m - m0)], rmean = lnm[2 * (m - m0) + 1];
+                    acc[2 * p][j] = igemm_ln_fold(a, nv, acc[2 * p][j], rstd, rmean);
+                    acc[2 * p + 1][j] = igemm_ln_fold(a, ng, acc[2 * p + 1][j], rstd, rmean);
+                }
                 h16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -350,12 +399,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int m = m0 + wm * (TM / 2) + j * 16 + li;
-        if (m >= a.M) continue;
+        float s1 = 0.f, s2 = 0.f;
+        if (m < a.M) {
+            float rstd = 1.f, rmean = 0.f;
+            if (a.ln_stat) { rstd = lnm[2 * (m - m0)]; rmean = lnm[2 * (m - m0) + 1]; }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
-            if (n >= a.Nout) continue;
-            igemm_epilogue(a, outp, resp, m, n, acc[i][j]);
+            for (int i = 0; i < NI; ++i) {
+                const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
+                if (n >= a.Nout) continue;
+                f32x4 v = acc[i][j];
+                if (a.ln_stat) v = igemm_ln_fold(a, n, v, rstd, rmean);
+                igemm_epilogue(a, outp, resp, m, n, v, s1, s2);
+            }
+        }
+        if (a.stat_out) {
+            // row statistics of what was just stored: the 4 lane groups hold different channels of the same token
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lg == 0 && m < a.M) {
+                float *dst = a.stat_out + ((long long)m * (2 * ntn) + tile_n * 2 + wn) * 2;
+                dst[0] = s1; dst[1] = s2;
+            }
         }
     }
 }
@@ -371,12 +435,49 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
     const float *wsp = a.ws + (long long)z * S * a.M * NoutP + (long long)m * NoutP + n;
     f32x4 v = *reinterpret_cast<const f32x4 *>(wsp);
     for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + (long long)s * a.M * NoutP);
-    igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
+    float s1 = 0.f, s2 = 0.f;
+    igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v, s1, s2);
+}
+
+// Split-K reduction with row statistics: one wave per token row (4 rows per block).  Used instead of the elementwise
+// kernel above when the op consumes a LayerNorm-folded input (needs the row's mean / rstd) and / or produces the row
+// statistics for a later fold (stat_out, P = 1).
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue_rows(IGemmArgs a, int S) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int NoutP = (a.Nout + 3) & ~3;
+    const long long z = blockIdx.z;
+    float rstd = 1.f, rmean = 0.f;
+    if (a.ln_stat) {
+        float s1 = 0.f, s2 = 0.f;
+        const float *sp = a.ln_stat + (long long)m * a.ln_P * 2;
+        for (int q = lane; q < a.ln_P; q += 64) { s1 += sp[2 * q]; s2 += sp[2 * q + 1]; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float inv = 1.0f / (float)(a.C1 + a.C2);
+        const float mean = s1 * inv;
+        rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+        rmean = rstd * mean;
+    }
+    const float *wsp = a.ws + z * S * a.M * NoutP + (long long)m * NoutP;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = lane * 4; n < NoutP; n += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(wsp + n);
+        for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + (long long)s * a.M * NoutP + n);
+        if (a.ln_stat) v = igemm_ln_fold(a, n, v, rstd, rmean);
+        igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v, s1, s2);
+    }
+    if (a.stat_out) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (lane == 0) { a.stat_out[(long long)m * 2] = s1; a.stat_out[(long long)m * 2 + 1] = s2; }
+    }
 }
 
 template <int TN, int TM, int MODE, int BK, int NS>
 static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
-    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
+    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16) + (size_t)TM * 2 * sizeof(float);   // ring + LN fold rows
     static bool attr_done = false;
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
         (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -418,6 +519,8 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.x1 = (const h16 *)op->p[0]; a.x2 = (const h16 *)op->p[1]; a.w = (const h16 *)op->p[2];
     a.bias = (const float *)op->p[3]; a.rowbias = (const float *)op->p[4];
     a.res = (const h16 *)op->p[5]; a.out = (h16 *)op->p[6]; a.zero = (const h16 *)op->p[7]; a.ws = (float *)op->p[8];
+    a.ln_stat = (const float *)op->p[9]; a.ln_colsum = (const float *)op->p[10]; a.stat_out = (float *)op->p[11];
+    a.ln_eps = op->f[0]; a.ln_P = (op->i[22] >> 8) & 0xff;
     a.taps = op->i[0]; a.C1 = op->i[1]; a.C2 = op->i[2]; a.ldx1 = op->i[3]; a.ldx2 = op->i[4];
     a.CinP = op->i[5]; a.B = op->i[6]; a.Hin = op->i[7]; a.Win = op->i[8]; a.Hout = op->i[9];
     a.Wout = op->i[10]; a.stride = op->i[11]; a.ups = op->i[12]; a.M = op->i[13]; a.Nout = op->i[14];
@@ -444,6 +547,13 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         l2d_set_error("igemm(tag %d): M != B*Hout*Wout", op->tag);
         return L2D_EINVAL;
     }
+    if ((a.ln_stat && (!a.ln_colsum || a.ln_P <= 0 || a.ln_eps <= 0.f)) || ((a.ln_stat || a.stat_out) && batch != 1) ||
+        (a.stat_out && a.epi == 1)) {
+        l2d_set_error("igemm(tag %d): invalid LayerNorm-fold arguments (ln_stat=%p colsum=%p P=%d eps=%g stat_out=%p batch=%d epi=%d)",
+                      op->tag, (const void *)a.ln_stat, (const void *)a.ln_colsum, a.ln_P, (double)a.ln_eps,
+                      (const void *)a.stat_out, batch, a.epi);
+        return L2D_EINVAL;
+    }
     L2D_DRY_RETURN();
     if (tile == 0) {
         long long big = (long long)((a.Nout + 127) / 128) * ((a.M + 127) / 128) * batch * a.splitk;
@@ -458,6 +568,9 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
     long long total = (long long)a.M * (NoutP / 4);
-    hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);
+    if (a.ln_stat || a.stat_out)
+        hipLaunchKernelGGL(igemm_splitk_epilogue_rows, dim3((unsigned)((a.M + 3) / 4), 1, batch), dim3(256), 0, s, a, a.splitk);
+    else
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);
     return l2d_check_launch("igemm_splitk_epilogue", op->tag);
 }
