@@ -62,7 +62,7 @@ enum {
  *   out = epi( rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n] ).
  *   p9 ln_stat [M][P][2] float row partial (sum, sumsq) or 0   p10 ln_colsum [Nout] float   f0 LayerNorm eps
  *   i22 bits 8..15 = P (partials per row)    p11 stat_out or 0: this launch writes the row partials of ITS output
- *   (P = 2 * ceil(Nout / tile) without split-K, 1 with) for a later folded consumer.  batch must be 1.
+ *   (P = ceil(Nout / tile) without split-K, 1 with) for a later folded consumer.  batch must be 1.
  *
  * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
  *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)

@@ -84,12 +84,12 @@ def colsum_of(packed: torch.Tensor) -> torch.Tensor:
 
 
 def stat_partials(Nout: int, tile: int, splitk: int) -> int:
-    """Row-statistics partials per row written by an igemm launch with `stat_out` (igemm.hip): one per half tile of
+    """Row-statistics partials per row written by an igemm launch with `stat_out` (igemm.hip): one per tile of
     output channels from the tile kernel, one per row from the split-K row epilogue."""
     if splitk > 1:
         return 1
     tn = 128 if (tile & 15) == 1 else 64
-    return 2 * ((Nout + tn - 1) // tn)
+    return (Nout + tn - 1) // tn
 
 
 def f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
