@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 2
+#define L2D_ABI_VERSION 1
 
 enum {
     L2D_OK = 0,
@@ -57,12 +57,6 @@ enum {
  *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch) i22 tile (0 auto, 1 = 128x128,
  *   2 = 64x64; + 16 = weight-tile-major block order: each XCD's L2 holds a band of output channels, for
  *   weight-dominated shapes) i23 pipeline variant (igemm.hip launch_p)
- *   LayerNorm fold (reference: nn.LayerNorm feeding to_q/to_k/to_v / the GEGLU projection, attention.py:221-270,
- *   motion_module.py:401-435): a consumer reads the RAW pre-norm tensor, its packed weights carry gamma, and
- *   out = epi( rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n] ).
- *   p9 ln_stat [M][P][2] float row partial (sum, sumsq) or 0   p10 ln_colsum [Nout] float   f0 LayerNorm eps
- *   i22 bits 8..15 = P (partials per row)    p11 stat_out or 0: this launch writes the row partials of ITS output
- *   (P = ceil(Nout / tile) without split-K, 1 with) for a later folded consumer.  batch must be 1.
  *
  * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
  *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)
@@ -119,7 +113,7 @@ enum {
 typedef struct l2d_op {
     int32_t kind;
     int32_t tag;          /* free for the host (plan index / layer id); echoed in error messages */
-    void *p[12];
+    void *p[10];
     int32_t i[24];
     int64_t l[4];
     float f[4];

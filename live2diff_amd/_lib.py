@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libl2d_hip.so")
 OP_IGEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_FLASH_ATTN = 1, 2, 3, 4, 5
 OP_TATTN_STREAM, OP_TATTN_WARMUP, OP_SKINNY_LINEAR, OP_TIMESTEP_EMBED = 6, 7, 8, 9
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_LCM_STEP, OP_COPY = 10, 11, 12, 13
-ABI_VERSION = 2
+ABI_VERSION = 1
 
 
 class L2DError(RuntimeError):
@@ -28,7 +28,7 @@ class L2dOp(ctypes.Structure):
     _fields_ = [
         ("kind", ctypes.c_int32),
         ("tag", ctypes.c_int32),
-        ("p", ctypes.c_void_p * 12),
+        ("p", ctypes.c_void_p * 10),
         ("i", ctypes.c_int32 * 24),
         ("l", ctypes.c_int64 * 4),
         ("f", ctypes.c_float * 4),

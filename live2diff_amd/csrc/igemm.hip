@@ -43,24 +43,13 @@ struct IGemmArgs {
     h16 *out;
     const h16 *zero;   // >= 16 bytes of zeros
     float *ws;         // split-K workspace [S][M][NoutP] fp32
-    // LayerNorm fold (consumer): x is the RAW pre-norm tensor, the weights carry gamma, and the epilogue turns
-    //   acc = sum_k x[m][k] W'[n][k]  into  rstd[m] * (acc - mean[m] * colsum[n]) (+ bias' ...), with
-    // mean / rstd of row m from `ln_P` partial (sum, sumsq) pairs written by the epilogue of the launch that
-    // produced x (`stat_out`): [M][P][2] floats, P = number of Nout tiles from the tile kernel, 1 from the split-K
-    // row epilogue.
-    const float *ln_stat, *ln_colsum;
-    float *stat_out;
-    float ln_eps;
-    int ln_P;
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
     int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order;
     long long sx1, sw, so, sres;
 };
 
-// fused epilogue for 4 consecutive output channels n..n+3 of token m; s1 / s2 accumulate the sum and the sum of
-// squares of the fp16 values actually stored (the row statistics a LayerNorm-folded consumer will read)
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v,
-                                               float &s1, float &s2, bool add_bias = true) {
+// fused epilogue for 4 consecutive output channels n..n+3 of token m
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v) {
     const float *rb = a.rowbias ? a.rowbias + (long long)(m / a.rows_per_bias) * a.ldrb : nullptr;
     if (n + 4 > a.Nout) {
         // ragged last channel group (Nout % 4 != 0, e.g. the swapped V^T GEMM with an odd token count)
@@ -68,17 +57,15 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
         for (int r = 0; r < 4; ++r) {
             if (n + r >= a.Nout) break;
             float y = v[r];
-            if (add_bias && a.bias) y += a.bias[n + r];
+            if (a.bias) y += a.bias[n + r];
             if (rb) y += rb[n + r];
             if (a.epi == 2) y = l2d_silu(y);
             if (resp) y += (float)resp[(long long)m * a.ldr + n + r];
-            const h16 yh = (h16)y;
-            outp[(long long)m * a.ldo + n + r] = yh;
-            s1 += (float)yh; s2 += (float)yh * (float)yh;
+            outp[(long long)m * a.ldo + n + r] = (h16)y;
         }
         return;
     }
-    if (add_bias && a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + n);
+    if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + n);
     if (rb) v += *reinterpret_cast<const f32x4 *>(rb + n);
     if (a.epi == 2) {
 #pragma unroll
@@ -91,30 +78,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
     }
     h16x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        o[r] = (h16)v[r];
-        s1 += (float)o[r]; s2 += (float)o[r] * (float)o[r];
-    }
+    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
     *reinterpret_cast<h16x4 *>(outp + (long long)m * a.ldo + n) = o;
 }
 
-// LayerNorm fold: acc -> rstd * acc - (rstd * mean) * colsum for 4 consecutive channels of one token
-__device__ __forceinline__ f32x4 igemm_ln_fold(const IGemmArgs &a, int n, f32x4 v, float rstd, float rmean) {
-    if (n + 4 > a.Nout) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < a.Nout) v[r] = rstd * v[r] - rmean * a.ln_colsum[n + r];
-        return v;
-    }
-    const f32x4 cs = *reinterpret_cast<const f32x4 *>(a.ln_colsum + n);
-    return rstd * v - rmean * cs;
-}
-
 // MODE 0: linear / 1x1 (taps = 1);  MODE 1: 3x3, single input, no upsample (fast gather);  MODE 2: 3x3 generic
-// LNF = 1: build with the LayerNorm-fold prologue / epilogue (consumer), LNF = 2: with the row-statistics output
-// (producer); linear layers only, never both in one launch.  Separate builds keep the register budget that lets
-// three 128x128 blocks share a CU: 156 (LNF 0) / 164 (LNF 1, 2) registers, against 172-176 with everything in one.
-template <int TN, int TM, int MODE, int BK, int NS, int LNF = 0>
+template <int TN, int TM, int MODE, int BK, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     constexpr int NI = TN / 32;        // 16-row fragments per wave along channels
     constexpr int MI = TM / 32;        // 16-col fragments per wave along tokens
@@ -319,36 +288,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (kb + s < ke) issue();
-    // LayerNorm fold: (rstd, rstd * mean) of this block's token rows -> LDS behind the ring.  Issued after the ring's
-    // first stages (the wait for these loads also covers them: in-order VMEM queue), read only in the epilogue.
-    float *lnm = reinterpret_cast<float *>(smem + NS * STAGE);      // [TM][2]
-    if (LNF == 1 && a.ln_stat && gridDim.y == 1) {
-        constexpr int TPR = 256 / TM;                // threads per row (2 or 4): the partial loads go out together
-        const int rl = tid / TPR, sub = tid % TPR;
-        const int m = m0 + rl;
-        float s1 = 0.f, s2 = 0.f;
-        if (m < a.M) {
-            const float2 *sp = reinterpret_cast<const float2 *>(a.ln_stat) + (long long)m * a.ln_P;
-#pragma unroll 4
-            for (int q = sub; q < a.ln_P; q += TPR) { const float2 v = sp[q]; s1 += v.x; s2 += v.y; }
-        }
-#pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if (sub == 0) {
-            const float inv = 1.0f / (float)Ctot;
-            const float mean = s1 * inv;
-            const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
-            lnm[2 * rl] = rstd;
-            lnm[2 * rl + 1] = rstd * mean;
-        }
-        // the tile's column sums and bias ride along: the epilogue then reads LDS instead of waiting on L2
-        if (tid < TN) {
-            const int n = n0 + tid;
-            lnm[2 * TM + tid] = n < a.Nout ? a.ln_colsum[n] : 0.f;
-            lnm[2 * TM + TN + tid] = (n < a.Nout && a.bias) ? a.bias[n] : 0.f;
-        }
-    }
-    const float *csl = lnm + 2 * TM, *bsl = csl + TN;      // [TN] colsum | [TN] bias (LNF = 1 only)
     // steady state: stage kt has landed when at most (NS-2) younger stages are still outstanding
     int kt = kb;
     for (; kt + (NS - 1) < ke; ++kt) {
@@ -394,17 +333,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
                 const int ng = nv + 16;                                         // packed row of the gate part
                 if (ng >= a.Nout) continue;
                 const int no = (n0 + wn * (TN / 2)) / 2 + p * 16 + lg * 4;      // output column
-                f32x4 bv, bg;
-                if (LNF == 1 && a.ln_stat) {
-                    const float rstd = lnm[2 * (m - m0)], rmean = lnm[2 * (m - m0) + 1];
-                    acc[2 * p][j] = rstd * acc[2 * p][j] - rmean * *reinterpret_cast<const f32x4 *>(csl + (nv - n0));
-                    acc[2 * p + 1][j] = rstd * acc[2 * p + 1][j] - rmean * *reinterpret_cast<const f32x4 *>(csl + (ng - n0));
-                    bv = *reinterpret_cast<const f32x4 *>(bsl + (nv - n0));
-                    bg = *reinterpret_cast<const f32x4 *>(bsl + (ng - n0));
-                } else {
-                    bv = *reinterpret_cast<const f32x4 *>(a.bias + nv);
-                    bg = *reinterpret_cast<const f32x4 *>(a.bias + ng);
-                }
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + nv);
+                const f32x4 bg = *reinterpret_cast<const f32x4 *>(a.bias + ng);
                 h16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -417,51 +347,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         }
         return;
     }
-    float st1[MI], st2[MI];
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int m = m0 + wm * (TM / 2) + j * 16 + li;
-        float s1 = 0.f, s2 = 0.f;
-        if (m < a.M) {
-            float rstd = 1.f, rmean = 0.f;
-            if (LNF == 1 && a.ln_stat) { rstd = lnm[2 * (m - m0)]; rmean = lnm[2 * (m - m0) + 1]; }
+        if (m >= a.M) continue;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
-                if (n >= a.Nout) continue;
-                f32x4 v = acc[i][j];
-                if (LNF == 1 && a.ln_stat) {
-                    // (columns past Nout hold 0 in LDS and are never stored)
-                    v = rstd * v - rmean * *reinterpret_cast<const f32x4 *>(csl + (n - n0)) + *reinterpret_cast<const f32x4 *>(bsl + (n - n0));
-                    igemm_epilogue(a, outp, resp, m, n, v, s1, s2, false);
-                } else {
-                    igemm_epilogue(a, outp, resp, m, n, v, s1, s2);
-                }
-            }
-        }
-        if (LNF == 2 && a.stat_out) {
-            // row statistics of what was just stored: the 4 lane groups hold different channels of the same token
-            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            st1[j] = s1; st2[j] = s2;
-        }
-    }
-    if (LNF == 2 && a.stat_out) {
-        // the two waves that split the channel tile meet in LDS (the ring is idle now): one partial per (row, tile)
-        float *scr = reinterpret_cast<float *>(smem);                // [2 (wn)][TM][2]
-        __syncthreads();                                             // every wave is done reading the ring
-        if (lg == 0) {
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int rl = wm * (TM / 2) + j * 16 + li;
-                scr[(wn * TM + rl) * 2] = st1[j];
-                scr[(wn * TM + rl) * 2 + 1] = st2[j];
-            }
-        }
-        __syncthreads();
-        if (tid < TM && m0 + tid < a.M) {
-            float2 *dst = reinterpret_cast<float2 *>(a.stat_out) + (long long)(m0 + tid) * ntn + tile_n;
-            *dst = make_float2(scr[tid * 2] + scr[(TM + tid) * 2], scr[tid * 2 + 1] + scr[(TM + tid) * 2 + 1]);
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
+            if (n >= a.Nout) continue;
+            igemm_epilogue(a, outp, resp, m, n, acc[i][j]);
         }
     }
 }
@@ -477,109 +371,46 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
     const float *wsp = a.ws + (long long)z * S * a.M * NoutP + (long long)m * NoutP + n;
     f32x4 v = *reinterpret_cast<const f32x4 *>(wsp);
     for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + (long long)s * a.M * NoutP);
-    float s1 = 0.f, s2 = 0.f;
-    igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v, s1, s2);
+    igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
 }
 
-// Split-K reduction with row statistics: RPB token rows per 256-thread block (1 row for wide outputs, so that a
-// 128-row level still gets 128 blocks; 4 = one wave per row for narrow ones).  Used instead of the elementwise kernel
-// above when the op consumes a LayerNorm-folded input (needs the row's mean / rstd) and / or produces the row
-// statistics for a later fold (stat_out, P = 1).
-template <int RPB>
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue_rows(IGemmArgs a, int S) {
-    constexpr int TPW = 256 / RPB;                 // threads per row
-    constexpr int WPR = TPW / 64;                  // waves per row
-    __shared__ float sh[4][2];                     // per-wave partial (sum, sumsq)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rl = tid / TPW, t = tid - rl * TPW;
-    const int m = blockIdx.x * RPB + rl;
-    const bool valid = m < a.M;
-    const int NoutP = (a.Nout + 3) & ~3;
-    const long long z = blockIdx.z;
-    float rstd = 1.f, rmean = 0.f;
-    if (a.ln_stat) {
-        float s1 = 0.f, s2 = 0.f;
-        if (valid) {
-            const float2 *sp = reinterpret_cast<const float2 *>(a.ln_stat) + (long long)m * a.ln_P;
-            for (int q = lane; q < a.ln_P; q += 64) { const float2 v = sp[q]; s1 += v.x; s2 += v.y; }   // every wave of the row
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        const float inv = 1.0f / (float)(a.C1 + a.C2);
-        const float mean = s1 * inv;
-        rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
-        rmean = rstd * mean;
-    }
-    const long long slab = (long long)a.M * NoutP;
-    const float *wsp = a.ws + z * S * slab + (long long)(valid ? m : 0) * NoutP;
-    float s1 = 0.f, s2 = 0.f;
-    if (valid) {
-#pragma unroll 2
-        for (int n = t * 4; n < NoutP; n += TPW * 4) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(wsp + n);
-#pragma unroll 8
-            for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + s * slab + n);
-            if (a.ln_stat) v = igemm_ln_fold(a, n, v, rstd, rmean);
-            igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v, s1, s2);
-        }
-    }
-    if (a.stat_out) {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if (WPR > 1) {
-            if (lane == 0) { sh[wave][0] = s1; sh[wave][1] = s2; }
-            __syncthreads();
-            if (t == 0) {
-                s1 = 0.f; s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WPR; ++w) { s1 += sh[rl * WPR + w][0]; s2 += sh[rl * WPR + w][1]; }
-            }
-        }
-        if (t == 0 && valid) { a.stat_out[(long long)m * 2] = s1; a.stat_out[(long long)m * 2 + 1] = s2; }
-    }
-}
-
-template <int TN, int TM, int MODE, int BK, int NS, int LNF>
+template <int TN, int TM, int MODE, int BK, int NS>
 static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
-    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16) + (LNF == 1 ? (size_t)(2 * TM + 2 * TN) * sizeof(float) : 0);   // ring (+ LN fold rows)
+    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
     static bool attr_done = false;
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr_done = true;
     }
     int ntn = (a.Nout + TN - 1) / TN, ntm = (a.M + TM - 1) / TM;
     dim3 grid(ntn * ntm, a.splitk, batch), block(256);
-    hipLaunchKernelGGL((igemm_kernel<TN, TM, MODE, BK, NS, LNF>), grid, block, LDS, s, a);
+    hipLaunchKernelGGL((igemm_kernel<TN, TM, MODE, BK, NS>), grid, block, LDS, s, a);
 }
 
 // pipeline variants (op.i[23]): 0 = BK32 x 4 stages, 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3,
 // 5 = BK64 x 2, 6 = BK128 x 2, 7 = BK128 x 3 (64x64 tile only), 8 = BK64 x 6 (64x64 only), 9 = BK64 x 4 (64x64 only)
-template <int TN, int TM, int MODE, int LNF>
+template <int TN, int TM, int MODE>
 static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
     switch (variant) {
-        case 0: launch_v<TN, TM, MODE, 32, 4, LNF>(a, batch, s); return L2D_OK;
-        case 1: launch_v<TN, TM, MODE, 64, 3, LNF>(a, batch, s); return L2D_OK;
-        case 2: launch_v<TN, TM, MODE, 64, 4, LNF>(a, batch, s); return L2D_OK;
-        case 3: launch_v<TN, TM, MODE, 32, 6, LNF>(a, batch, s); return L2D_OK;
-        case 4: launch_v<TN, TM, MODE, 32, 3, LNF>(a, batch, s); return L2D_OK;
-        case 5: launch_v<TN, TM, MODE, 64, 2, LNF>(a, batch, s); return L2D_OK;
-        case 6: launch_v<TN, TM, MODE, 128, 2, LNF>(a, batch, s); return L2D_OK;
-        case 7: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 128, 3, LNF>(a, batch, s); return L2D_OK;
-        case 8: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 6, LNF>(a, batch, s); return L2D_OK;
-        case 9: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 4, LNF>(a, batch, s); return L2D_OK;
+        case 0: launch_v<TN, TM, MODE, 32, 4>(a, batch, s); return L2D_OK;
+        case 1: launch_v<TN, TM, MODE, 64, 3>(a, batch, s); return L2D_OK;
+        case 2: launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK;
+        case 3: launch_v<TN, TM, MODE, 32, 6>(a, batch, s); return L2D_OK;
+        case 4: launch_v<TN, TM, MODE, 32, 3>(a, batch, s); return L2D_OK;
+        case 5: launch_v<TN, TM, MODE, 64, 2>(a, batch, s); return L2D_OK;
+        case 6: launch_v<TN, TM, MODE, 128, 2>(a, batch, s); return L2D_OK;
+        case 7: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 128, 3>(a, batch, s); return L2D_OK;
+        case 8: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 6>(a, batch, s); return L2D_OK;
+        case 9: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK;
     }
     return L2D_EINVAL;
 }
 
 template <int TN, int TM>
 static int launch_t(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
-    if (a.taps == 1) {
-        if (a.ln_stat) return launch_p<TN, TM, 0, 1>(a, batch, variant, s);
-        if (a.stat_out) return launch_p<TN, TM, 0, 2>(a, batch, variant, s);
-        return launch_p<TN, TM, 0, 0>(a, batch, variant, s);
-    }
-    if (a.C2 == 0 && a.ups == 0) return launch_p<TN, TM, 1, 0>(a, batch, variant, s);
-    return launch_p<TN, TM, 2, 0>(a, batch, variant, s);
+    if (a.taps == 1) return launch_p<TN, TM, 0>(a, batch, variant, s);
+    if (a.C2 == 0 && a.ups == 0) return launch_p<TN, TM, 1>(a, batch, variant, s);
+    return launch_p<TN, TM, 2>(a, batch, variant, s);
 }
 
 int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
@@ -587,8 +418,6 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.x1 = (const h16 *)op->p[0]; a.x2 = (const h16 *)op->p[1]; a.w = (const h16 *)op->p[2];
     a.bias = (const float *)op->p[3]; a.rowbias = (const float *)op->p[4];
     a.res = (const h16 *)op->p[5]; a.out = (h16 *)op->p[6]; a.zero = (const h16 *)op->p[7]; a.ws = (float *)op->p[8];
-    a.ln_stat = (const float *)op->p[9]; a.ln_colsum = (const float *)op->p[10]; a.stat_out = (float *)op->p[11];
-    a.ln_eps = op->f[0]; a.ln_P = (op->i[22] >> 8) & 0xff;
     a.taps = op->i[0]; a.C1 = op->i[1]; a.C2 = op->i[2]; a.ldx1 = op->i[3]; a.ldx2 = op->i[4];
     a.CinP = op->i[5]; a.B = op->i[6]; a.Hin = op->i[7]; a.Win = op->i[8]; a.Hout = op->i[9];
     a.Wout = op->i[10]; a.stride = op->i[11]; a.ups = op->i[12]; a.M = op->i[13]; a.Nout = op->i[14];
@@ -615,13 +444,6 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         l2d_set_error("igemm(tag %d): M != B*Hout*Wout", op->tag);
         return L2D_EINVAL;
     }
-    if ((a.ln_stat && (!a.ln_colsum || a.ln_P <= 0 || a.ln_eps <= 0.f)) || ((a.ln_stat || a.stat_out) && batch != 1) ||
-        (a.stat_out && (a.epi == 1 || a.ln_stat)) || ((a.ln_stat || a.stat_out) && a.taps != 1)) {
-        l2d_set_error("igemm(tag %d): invalid LayerNorm-fold arguments (ln_stat=%p colsum=%p P=%d eps=%g stat_out=%p batch=%d epi=%d)",
-                      op->tag, (const void *)a.ln_stat, (const void *)a.ln_colsum, a.ln_P, (double)a.ln_eps,
-                      (const void *)a.stat_out, batch, a.epi);
-        return L2D_EINVAL;
-    }
     L2D_DRY_RETURN();
     if (tile == 0) {
         long long big = (long long)((a.Nout + 127) / 128) * ((a.M + 127) / 128) * batch * a.splitk;
@@ -636,14 +458,6 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
     long long total = (long long)a.M * (NoutP / 4);
-    if (a.ln_stat || a.stat_out) {
-        if (NoutP >= 1024)
-            hipLaunchKernelGGL(igemm_splitk_epilogue_rows<1>, dim3((unsigned)a.M, 1, batch), dim3(256), 0, s, a, a.splitk);
-        else if (NoutP >= 512)
-            hipLaunchKernelGGL(igemm_splitk_epilogue_rows<2>, dim3((unsigned)((a.M + 1) / 2), 1, batch), dim3(256), 0, s, a, a.splitk);
-        else
-            hipLaunchKernelGGL(igemm_splitk_epilogue_rows<4>, dim3((unsigned)((a.M + 3) / 4), 1, batch), dim3(256), 0, s, a, a.splitk);
-    } else
-        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);
+    hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);
     return l2d_check_launch("igemm_splitk_epilogue", op->tag);
 }

@@ -62,36 +62,6 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     return pack_linear(w[perm]), b[perm].float().contiguous()
 
 
-def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
-    """LayerNorm folded into the Linear that consumes it:  LN(x) @ W^T + b  =  rstd * (x @ W'^T - mean * colsum) + b'
-    with W' = W * gamma (rounded to fp16, what the GEMM multiplies), colsum[n] = sum_k W'[n][k] (of the ROUNDED
-    weights, so the mean term cancels exactly what the MFMA accumulated) and b' = b + W @ beta.
-    Returns (W' fp16 [Nout, K], b' fp32 [Nout]); the column sums are taken after packing (`colsum_of`)."""
-    w32 = w.reshape(w.shape[0], -1).float()
-    wf = (w32 * gamma.float()[None, :]).to(torch.float16)
-    bf = w32 @ beta.float()
-    if b is not None:
-        bf = bf + b.float()
-    return wf, bf.contiguous()
-
-
-def colsum_of(packed: torch.Tensor) -> torch.Tensor:
-    """Row sums of a packed fp16 weight matrix as fp32, padded to a multiple of 4 (vector loads in the epilogue)."""
-    cs = packed.float().sum(1)
-    out = torch.zeros(round_up(cs.numel(), 4), dtype=torch.float32, device=packed.device)
-    out[:cs.numel()] = cs
-    return out
-
-
-def stat_partials(Nout: int, tile: int, splitk: int) -> int:
-    """Row-statistics partials per row written by an igemm launch with `stat_out` (igemm.hip): one per tile of
-    output channels from the tile kernel, one per row from the split-K row epilogue."""
-    if splitk > 1:
-        return 1
-    tn = 128 if (tile & 15) == 1 else 64
-    return (Nout + tn - 1) // tn
-
-
 def f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.float().contiguous()
 
@@ -161,12 +131,9 @@ _TUNED = _load_tuned()
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5, order=0, ln_stat=None, ln_P=0, ln_colsum=None, ln_eps=1e-5, stat_out=None):
+          variant=5, order=0):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
-    splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements.
-    LayerNorm fold (include/l2d.h): `ln_stat` [M][ln_P][2] fp32 row partials of x1 + `ln_colsum` [Nout] fp32 make this
-    launch apply LayerNorm(x1) through its epilogue (weights must carry gamma, bias the beta term: `fold_layernorm`);
-    `stat_out` [M][P][2] makes it emit the row partials of its own output (P = `stat_partials(...)`)."""
+    splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
     op.kind = _lib.OP_IGEMM
     es = 2
@@ -180,13 +147,6 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     op.p[6] = _ptr(_h(out)) + out_off * es
     op.p[7] = _ptr(zp)
     op.p[8] = _ptr(ws)
-    op.p[9], op.p[10], op.p[11] = _ptr(ln_stat), _ptr(ln_colsum), _ptr(stat_out)
-    if ln_stat is not None:
-        assert ln_stat.dtype == torch.float32 and ln_colsum.dtype == torch.float32 and 0 < ln_P < 256
-        assert ln_stat.numel() >= M * ln_P * 2 and ln_colsum.numel() >= round_up(Nout, 4)
-        op.f[0] = float(ln_eps)
-    if stat_out is not None:
-        assert stat_out.dtype == torch.float32 and stat_out.numel() >= M * stat_partials(Nout, tile, splitk) * 2
     if bias is not None:
         assert bias.dtype == torch.float32
     if rowbias is not None:
@@ -194,11 +154,11 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     if splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
-            rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order) + 256 * (int(ln_P) if ln_stat is not None else 0), variant]
+            rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order), variant]
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
-    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, ln_stat, ln_colsum, stat_out)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):

@@ -29,8 +29,7 @@ from . import _lib, ops
 from .config import UNetConfig, motion_module_layout
 from .ops import round_up
 
-TEXT_PAD = 80          # 77 CLIP tokens padded to a multiple of 4 (igemm stores 4 channels per lane)
-LN_EPS = 1e-5          # nn.LayerNorm default, as in the reference's transformer blocks
+TEXT_PAD = 80   # 77 CLIP tokens padded to a multiple of 4 (igemm stores 4 channels per lane)
 
 
 class UNetOutput(dict):
@@ -87,11 +86,10 @@ class _Arena:
 
 class _Act:
     """channels-last activation: buf holds [B*H*W, C] halfs (ld == C)."""
-    __slots__ = ("buf", "C", "H", "W", "stats")
+    __slots__ = ("buf", "C", "H", "W")
 
     def __init__(self, buf, C, H, W):
         self.buf, self.C, self.H, self.W = buf, C, H, W
-        self.stats = None      # (fp32 row partials [M][P][2], P) when the producing GEMM emitted LayerNorm statistics
 
 
 class HipStreamingUNet:
@@ -156,22 +154,9 @@ class HipStreamingUNet:
             W[name + ".g"] = g(name + ".weight").to(torch.float16).contiguous()
             W[name + ".beta"] = g(name + ".bias").to(torch.float16).contiguous()
 
-        def lin_fold(name, norm_name, wkey=None, weight=None, bias=True):
-            """Linear with the LayerNorm `norm_name` that feeds it folded in (ops.fold_layernorm)."""
-            w = weight if weight is not None else g(name + ".weight")
-            b = g(name + ".bias") if (bias and weight is None) else None
-            wf, bf = ops.fold_layernorm(w, b, g(norm_name + ".weight"), g(norm_name + ".bias"))
-            key = wkey or name
-            W[key + ".w" if wkey is None else key] = ops.pack_linear(wf)
-            W[key + ".b"] = bf
-            W[key + ".cs"] = ops.colsum_of(W[key + ".w" if wkey is None else key])
-
-        def ff(name, norm_name):
-            wf, bf = ops.fold_layernorm(g(name + ".net.0.proj.weight"), g(name + ".net.0.proj.bias"),
-                                        g(norm_name + ".weight"), g(norm_name + ".bias"))
-            w, b = ops.pack_geglu(wf, bf)
+        def ff(name):
+            w, b = ops.pack_geglu(g(name + ".net.0.proj.weight"), g(name + ".net.0.proj.bias"))
             W[name + ".w1"], W[name + ".b1"] = w, b
-            W[name + ".cs1"] = ops.colsum_of(w)
             lin(name + ".net.2")
 
         self.temb_names, self.temb_offsets = [], {}
@@ -190,16 +175,17 @@ class HipStreamingUNet:
         def spatial(name):
             norm(name + ".norm"); lin(name + ".proj_in"); lin(name + ".proj_out")
             b = name + ".transformer_blocks.0"
-            norm(b + ".norm1")      # norm2 / norm3 are folded into attn2.to_q / the GEGLU projection
+            for n in ("norm1", "norm2", "norm3"):
+                norm(b + "." + n)
             W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([g(b + ".attn1.to_q.weight"), g(b + ".attn1.to_k.weight")], 0))
             W[b + ".attn1.v"] = ops.pack_linear(g(b + ".attn1.to_v.weight"))
             lin(b + ".attn1.to_out.0")
-            lin_fold(b + ".attn2.to_q", b + ".norm2", bias=False)
+            lin(b + ".attn2.to_q", bias=False)
             self.text_offsets[name] = sum(t.shape[0] for t in text_k)
             text_k.append(g(b + ".attn2.to_k.weight").to(torch.float16))
             text_v.append(g(b + ".attn2.to_v.weight").to(torch.float16))
             lin(b + ".attn2.to_out.0")
-            ff(b + ".ff", b + ".norm3")
+            ff(b + ".ff")
 
         self.pe_tables = {}
 
@@ -214,12 +200,14 @@ class HipStreamingUNet:
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
                 wq, wk, wv = g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")
-                lin_fold(None, b + f".norms.{j}", wkey=a + ".qkv", weight=torch.cat([wq, wk, wv], 0))
+                W[a + ".qkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0))
                 # pre-projected positional encodings (reference prepare_pe_buffer, stream_motion_module.py:79-97)
                 for nm, w_ in (("q_pe", wq), ("k_pe", wk), ("v_pe", wv)):
                     W[a + "." + nm] = (pe @ w_.float().t()).to(torch.float16).contiguous()
                 lin(a + ".to_out.0")
-            ff(b + ".ff", b + ".ff_norm")
+                norm(b + f".norms.{j}")
+            norm(b + ".ff_norm")
+            ff(b + ".ff")
 
         conv3("conv_in")
         conv3("flow_conv_in.conv_in")
@@ -280,7 +268,7 @@ class HipStreamingUNet:
             pl.append(op, *keep)
             return op
 
-        def gemm(x1, wt, out, want_stats=False, ln=None, cs=None, **kw):
+        def gemm(x1, wt, out, **kw):
             """igemm with the (tile, split-K) schedule chosen for its shape; the fp32 split-K workspace comes from
             the arena and is released right after (stream order makes the reuse safe)."""
             batch, taps = kw.get("batch", 1), kw.get("taps", 1)
@@ -299,16 +287,8 @@ class HipStreamingUNet:
             wbytes = kw["Nout"] * taps * kw["CinP"]
             xbytes = kw["M"] * (kw["C1"] + kw.get("C2", 0))
             order = {"0": 0, "1": 1}.get(os.environ.get("L2D_IGEMM_ORDER", ""), int(wbytes > xbytes))
-            stats = None
-            if want_stats:      # row (sum, sumsq) partials of the output, for a LayerNorm folded into its consumer
-                P = ops.stat_partials(kw["Nout"], tile, S)
-                stats = (ar.alloc(kw["M"] * P * 2, torch.float32), P)
-            if ln is not None:
-                kw = dict(kw, ln_stat=ln[0], ln_P=ln[1], ln_colsum=cs, ln_eps=LN_EPS)
-            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order,
-                               stat_out=(stats[0] if stats else None), **kw))
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order, **kw))
             ar.release(ws)
-            st.last_stats = stats
             return op
 
         # ---- static inputs
@@ -329,9 +309,6 @@ class HipStreamingUNet:
         def free(a: Optional[_Act]):
             if a is not None:
                 ar.release(a.buf)
-                if a.stats is not None:
-                    ar.release(a.stats[0])
-                    a.stats = None
 
         def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
             T = x.H * x.W
@@ -375,18 +352,13 @@ class HipStreamingUNet:
             gemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
                           res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw)
 
-        def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None,
-                   stats=False, fold=False) -> _Act:
-            """stats: also emit the output's row statistics (for a LayerNorm folded into a later consumer);
-            fold: x is the raw input of a LayerNorm whose affine lives in this layer's packed weights."""
+        def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None) -> _Act:
             wt = W[wkey or (name + ".w")]
             out = new_act(wt.shape[0], x.H, x.W)
-            lnkw = dict(ln=x.stats, cs=W[name + ".cs"]) if fold else {}
             linear_raw(x.buf, B * x.H * x.W, x.C, x.C, wt, out.buf, wt.shape[0], bias=(W[name + ".b"] if bias else None),
                        res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
                        x2=(x2.buf if x2 is not None else None), C2=(x2.C if x2 is not None else 0),
-                       ldx2=(x2.C if x2 is not None else 0), want_stats=stats, **lnkw)
-            out.stats = st.last_stats
+                       ldx2=(x2.C if x2 is not None else 0))
             return out
 
         def layernorm(x: _Act, name) -> _Act:
@@ -395,12 +367,10 @@ class HipStreamingUNet:
             return out
 
         def geglu_ff(x: _Act, name, res: _Act) -> _Act:
-            """x is the RAW residual stream: the FF's LayerNorm is folded into the GEGLU projection."""
             w1 = W[name + ".w1"]
             c4 = w1.shape[0] // 2
             hid = new_act(c4, x.H, x.W)
-            linear_raw(x.buf, B * x.H * x.W, x.C, x.C, w1, hid.buf, c4, bias=W[name + ".b1"], epi=1, ln=x.stats,
-                       cs=W[name + ".cs1"])
+            linear_raw(x.buf, B * x.H * x.W, x.C, x.C, w1, hid.buf, c4, bias=W[name + ".b1"], epi=1)
             out = linear(hid, name + ".net.2", res=res)
             free(hid)
             return out
@@ -443,11 +413,12 @@ class HipStreamingUNet:
             add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
                                ldo=C, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, k_off=C))
             ar.release(qk); ar.release(vt)
-            y2 = linear(ao, b + ".attn1.to_out.0", res=y, stats=True)
+            y2 = linear(ao, b + ".attn1.to_out.0", res=y)
             free(ao); free(y)
-            # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start);
-            # norm2 is folded into to_q, norm3 into the GEGLU projection
-            q2 = linear(y2, b + ".attn2.to_q", fold=True)
+            # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start)
+            n2 = layernorm(y2, b + ".norm2")
+            q2 = linear(n2, b + ".attn2.to_q", bias=False)
+            free(n2)
             off = self.text_offsets[name]
             ao = new_act(C, x.H, x.W)
             add(ops.flash_attn(q2.buf, st.text_k, st.text_vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=st.text_len,
@@ -455,10 +426,11 @@ class HipStreamingUNet:
                                sk=(TEXT_PAD * self.text_total if Bt > 1 else 0),
                                svt=(self.text_total * TEXT_PAD if Bt > 1 else 0), so=T * C, k_off=off, vt_off=off * TEXT_PAD))
             free(q2)
-            y3 = linear(ao, b + ".attn2.to_out.0", res=y2, stats=True)
+            y3 = linear(ao, b + ".attn2.to_out.0", res=y2)
             free(ao); free(y2)
-            y4 = geglu_ff(y3, b + ".ff", res=y3)
-            free(y3)
+            n3 = layernorm(y3, b + ".norm3")
+            y4 = geglu_ff(n3, b + ".ff", res=y3)
+            free(n3); free(y3)
             out = linear(y4, name + ".proj_out", res=x)
             free(y4)
             return out
@@ -467,13 +439,15 @@ class HipStreamingUNet:
             T, C = x.H * x.W, x.C
             t = name + ".temporal_transformer"
             hn = gn(x, t + ".norm", cfg.transformer_norm_eps, False)
-            y = linear(hn, t + ".proj_in", stats=True)
+            y = linear(hn, t + ".proj_in")
             free(hn)
             b = t + ".transformer_blocks.0"
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
-                qkv = ar.alloc(B * T * 3 * C)     # norms.j is folded into the fused q|k|v projection
-                linear_raw(y.buf, B * T, C, C, W[a + ".qkv"], qkv, 3 * C, bias=W[a + ".qkv.b"], ln=y.stats, cs=W[a + ".qkv.cs"])
+                nrm = layernorm(y, b + f".norms.{j}")
+                qkv = ar.alloc(B * T * 3 * C)
+                linear_raw(nrm.buf, B * T, C, C, W[a + ".qkv"], qkv, 3 * C)
+                free(nrm)
                 ao = new_act(C, x.H, x.W)
                 idx = idx_base + j
                 cache = kv_cache[idx]
@@ -486,11 +460,12 @@ class HipStreamingUNet:
                                               F=B, T=T, C=C, L=L, H=cfg.temporal_heads))
                 st.tattn_ops.append((op.tag, idx))
                 ar.release(qkv)
-                y2 = linear(ao, a + ".to_out.0", res=y, stats=True)
+                y2 = linear(ao, a + ".to_out.0", res=y)
                 free(ao); free(y)
                 y = y2
-            y2 = geglu_ff(y, b + ".ff", res=y)
-            free(y)
+            nrm = layernorm(y, b + ".ff_norm")
+            y2 = geglu_ff(nrm, b + ".ff", res=y)
+            free(nrm); free(y)
             out = linear(y2, t + ".proj_out", res=x)
             free(y2)
             return out

@@ -148,66 +148,6 @@ def test_igemm_schedule_matches_plain(L):
     check(outs[2], outs[0], tol=1e-3, what="big split vs plain")
 
 
-# ----------------------------------------------------------------------------- igemm: LayerNorm fold
-def _producer(L, M, K, N, tile, S, seed=1):
-    """x = x0 @ w0^T + b0 + r0 through igemm with stat_out: returns (x fp16 on device, stats [M][P][2], P)"""
-    x0 = rnd(M, K, seed=seed)
-    w0 = rnd(N, K, seed=seed + 1, scale=K ** -0.5)
-    b0 = (rnd(N, seed=seed + 2).float() + 0.7)          # non-zero row mean
-    r0 = rnd(M, N, seed=seed + 3)
-    wp = L.pack_linear(w0.to(DEV))
-    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    P = L.stat_partials(N, tile, S)
-    stats = torch.full((M * P * 2,), float("nan"), dtype=torch.float32, device=DEV)
-    ws = torch.empty(S * M * ((N + 3) // 4 * 4), dtype=torch.float32, device=DEV) if S > 1 else None
-    L.run(L.igemm(x0.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, CinP=wp.shape[1], ldo=N, bias=b0.to(DEV), res=r0.to(DEV),
-                  ldr=N, tile=tile, splitk=S, ws=ws, stat_out=stats))
-    torch.cuda.synchronize()
-    ref = x0.float() @ w0.float().t() + b0 + r0.float()
-    return out, stats, P, ref
-
-
-@pytest.mark.parametrize("M,K,N,tile,S", [(300, 320, 320, 2, 1), (8192, 320, 320, 2, 1), (512, 1280, 1280, 1, 1),
-                                          (128, 1280, 1280, 2, 4), (512, 640, 200, 1, 2), (70, 64, 68, 2, 1)])
-def test_igemm_row_stats(L, M, K, N, tile, S):
-    """stat_out = per-row (sum, sum of squares) partials of the fp16 values the launch stored"""
-    out, stats, P, ref = _producer(L, M, K, N, tile, S)
-    check(out, ref, what="producer output")
-    st = stats.view(M, P, 2).sum(1).cpu().double()
-    o = out.cpu().double()
-    assert torch.allclose(st[:, 0], o.sum(1), rtol=1e-4, atol=1e-2), (st[:3, 0], o.sum(1)[:3])
-    assert torch.allclose(st[:, 1], (o * o).sum(1), rtol=1e-4, atol=1e-2)
-
-
-@pytest.mark.parametrize("M,C,N,ptile,pS,tile,S,geglu", [(300, 320, 960, 2, 1, 2, 1, False), (8192, 320, 960, 2, 1, 1, 1, False),
-                                                         (512, 1280, 1280, 1, 1, 2, 1, False), (128, 1280, 1280, 2, 4, 2, 4, False),
-                                                         (2048, 640, 5120, 2, 1, 1, 1, True), (128, 1280, 10240, 2, 4, 2, 1, True),
-                                                         (512, 640, 640, 1, 2, 1, 3, False)])
-def test_igemm_layernorm_fold(L, M, C, N, ptile, pS, tile, S, geglu):
-    """LayerNorm(x) @ W^T + b computed as a GEMM on the RAW x with gamma in the weights and the row statistics
-    (written by the producer's epilogue) applied in the consumer's epilogue"""
-    x, stats, P, _ = _producer(L, M, 256, C, ptile, pS, seed=11)
-    gamma = (rnd(C, seed=21).float() * 0.3 + 1.0)
-    beta = rnd(C, seed=22).float() * 0.3
-    w = rnd(N, C, seed=23, scale=C ** -0.5)
-    b = rnd(N, seed=24).float()
-    h = F.layer_norm(x.float().cpu(), (C,), gamma, beta, 1e-5) @ w.float().t() + b
-    wf, bf = L.fold_layernorm(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV))
-    if geglu:
-        ref = h[:, :N // 2] * F.gelu(h[:, N // 2:])
-        wp, bp = L.pack_geglu(wf, bf)
-        nout_store, epi = N // 2, 1
-    else:
-        ref, wp, bp, nout_store, epi = h, L.pack_linear(wf), bf, N, 0
-    cs = L.colsum_of(wp)
-    out = torch.empty(M, nout_store, dtype=torch.float16, device=DEV)
-    ws = torch.empty(S * M * N, dtype=torch.float32, device=DEV) if S > 1 else None
-    L.run(L.igemm(x, wp, out, M=M, Nout=N, C1=C, ldx1=C, CinP=wp.shape[1], ldo=nout_store, bias=bp, epi=epi, tile=tile,
-                  splitk=S, ws=ws, ln_stat=stats, ln_P=P, ln_colsum=cs, ln_eps=1e-5))
-    torch.cuda.synchronize()
-    check(out, ref, tol=3e-3, what=f"layernorm fold M{M} C{C} N{N} geglu{int(geglu)} S{S}")
-
-
 # ----------------------------------------------------------------------------- igemm: conv
 @pytest.mark.parametrize("cin,cout,H,W,stride,ups", [(64, 64, 8, 8, 1, 0), (8, 64, 12, 10, 1, 0), (96, 64, 9, 7, 1, 0),
                                                      (64, 128, 12, 10, 2, 0), (64, 64, 5, 6, 1, 1), (320, 320, 32, 32, 1, 0),

@@ -86,8 +86,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib.l2d_abi_version() == 2
-    assert ctypes.sizeof(_lib.L2dOp) == 248
+    assert _lib.lib.l2d_abi_version() == 1
+    assert ctypes.sizeof(_lib.L2dOp) == 232
     # error path without a device: refused loudly, no fallback
     ops = (_lib.L2dOp * 1)()
     ops[0].kind = 99
