@@ -40,10 +40,11 @@ struct FACfg {
     static constexpr int VCH = (VTOT + 255) / 256;
     static constexpr int TILE_HALFS = 64 * KROW + D16 * 16 * VROW;
     static constexpr int NBUF = (TILE_HALFS * 2 * 2 <= 65536) ? 2 : 1;
+    static constexpr bool ONES = (D % 16) != 0;        // a spare padded row of V^T carries ones (see load_tiles)
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
+__device__ __forceinline__ void flash_attn_body(const FAArgs &a) {
     using Cf = FACfg<D>;
     constexpr int DQK = Cf::DQK, KK = Cf::KK, D16 = Cf::D16, KROW = Cf::KROW, VROW = Cf::VROW;
     constexpr int KCH = Cf::KCH, VCH = Cf::VCH, NBUF = Cf::NBUF;
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
             int dd = id >> 3, c = id & 7;
             int key = key0 + c * 8;
             h16x8 v = l2d_zero8();
+            if (Cf::ONES && dd == D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (h16)1.0f;   // ones row: O^T[D][q] = sum_k p(q,k), the softmax denominator
+            }
             if (id < Cf::VTOT && dd < D && key < a.Tk) {
                 v = l2d_ld8(vp + (long long)dd * a.ldvt + key);
                 if (key + 8 > a.Tk) {
@@ -129,56 +134,57 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
         const h16 *Vs = Ks + 64 * KROW;
 
         f32x4 sacc[4][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qs = 0; qs < 2; ++qs) sacc[ks][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 h16x8 kf = l2d_ld8(Ks + (ks * 16 + li) * KROW + kk * 32 + lg * 8);
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs)
-                    sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][kk], sacc[ks][qs], 0, 0, 0);
+                for (int qs = 0; qs < 2; ++qs)   // first K step accumulates onto the inline constant 0: no zero-fill
+                    sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][kk], kk == 0 ? zero4 : sacc[ks][qs], 0, 0, 0);
             }
-        // scale to the exp2 domain, mask keys beyond Tk (last tile only)
-        const bool tail = (kt + 1) * 64 > a.Tk;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = sacc[ks][qs][r] * c2e;
-                    if (tail && (kt * 64 + ks * 16 + lg * 4 + r) >= a.Tk) v = -1.0e30f;
-                    sacc[ks][qs][r] = v;
-                }
-        h16x8 pf[2][2];   // [c2][qs]
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            float mx = sacc[0][qs][0];
+        // Softmax in the exp2 domain on the RAW scores: p = exp2(s * c2e - mref * c2e) is one FMA + one v_exp_f32.
+        // `mref` is a per-row reference, not the running maximum: it is only raised (and O, l rescaled) when some row
+        // of the wave exceeds it by more than 2^8 -- p <= 256 is exact enough in fp16 and l, O are fp32 -- so after the
+        // first tile the rescale branch (wave-uniform) is almost never taken.  Keys beyond Tk exist in the last tile only.
+        if ((kt + 1) * 64 > a.Tk) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[ks][qs][r]);
+                for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((kt * 64 + ks * 16 + lg * 4 + r) >= a.Tk) sacc[ks][qs][r] = -3.0e38f;
+        }
+        h16x8 pf[2][2];   // [c2][qs]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = fmaxf(fmaxf(sacc[0][qs][0], sacc[0][qs][1]), fmaxf(sacc[0][qs][2], sacc[0][qs][3]));
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks)
+                mx = fmaxf(fmaxf(mx, fmaxf(sacc[ks][qs][0], sacc[ks][qs][1])), fmaxf(sacc[ks][qs][2], sacc[ks][qs][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrow[qs], mx);
-            const float alpha = exp2f(mrow[qs] - mnew);
-            mrow[qs] = mnew;
+            if (__any((mx - mrow[qs]) * c2e > 8.0f)) {
+                const float mnew = fmaxf(mrow[qs], mx);
+                const float alpha = __builtin_amdgcn_exp2f((mrow[qs] - mnew) * c2e);
+                mrow[qs] = mnew;
+                lrow[qs] *= alpha;
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
+            }
+            const float mneg = -mrow[qs] * c2e;
             float psum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pv = exp2f(sacc[ks][qs][r] - mnew);
-                    psum += pv;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[ks][qs][r], c2e, mneg));
+                    if (!Cf::ONES) psum += pv;
                     pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
                 }
-            lrow[qs] = lrow[qs] * alpha + psum;
-#pragma unroll
-            for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
+            if (!Cf::ONES) lrow[qs] += psum;
         }
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
@@ -204,9 +210,15 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
     }
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
-        float l = lrow[qs];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if (Cf::ONES) {
+            // O^T row D (fragment D/16, lane group (D%16)/4, register D%4) holds the denominator of query li
+            l = __shfl(oacc[D / 16][qs][D % 4], ((D % 16) / 4) * 16 + li, 64);
+        } else {
+            l = lrow[qs];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qr = q0 + qs * 16 + li;
         if (qr >= a.Tq) continue;
@@ -222,10 +234,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) {
     }
 }
 
+// Two entry points over the same body: with the occupancy hint the compiler keeps the accumulators in plain VGPRs (no
+// AGPR <-> VGPR copies around every softmax) and fits d = 40 in 162 and d = 80 in 200 registers (188 / 264 without:
+// d = 80 ran ONE wave per SIMD); d = 160 would spill under the hint and keeps the default budget.
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(FAArgs a) { flash_attn_body<D>(a); }
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void flash_attn_kernel_w2(FAArgs a) { flash_attn_body<D>(a); }
+
 template <int D>
 static void launch_fa(const FAArgs &a, hipStream_t s) {
     dim3 grid((a.Tq + 127) / 128, a.H, a.B);
-    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, s, a);
+    if (D <= 80) hipLaunchKernelGGL((flash_attn_kernel_w2<D>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, s, a);
 }
 
 int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
