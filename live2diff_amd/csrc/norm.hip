@@ -43,10 +43,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-        for (int t = t0 + prow; t < t1; t += PR) {
-            h16x8 v = gn_load(a, (long long)b * a.T + t, vc);
+        // 4 rows per trip, loads first: the loop is one dependent HBM/L2 round trip per iteration otherwise
+        for (int t = t0 + prow; t < t1; t += 4 * PR) {
+            h16x8 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * PR;
+                v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = (float)v[u][e]; s[e] += f; q[e] += f * f; }
         }
         // fold the 8 channels into their groups (runs of equal group id), then LDS atomics
         int g_prev = (vc * 8) / cpg;
@@ -110,16 +118,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
             sc[e] = s_rstd[g] * (float)gm[e];
             sh[e] = (float)bt[e] - s_mean[g] * sc[e];
         }
-        for (int t = t0 + prow; t < t1; t += PR) {
-            long long pix = (long long)b * a.T + t;
-            h16x8 v = gn_load(a, pix, vc), o;
+        for (int t = t0 + prow; t < t1; t += 4 * PR) {     // 4 rows per trip, loads first (see gn_stats)
+            h16x8 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = (float)v[e] * sc[e] + sh[e];
-                if (a.silu) y = l2d_silu(y);
-                o[e] = (h16)y;
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * PR;
+                v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
             }
-            l2d_st8(a.out + pix * C + vc * 8, o);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * PR;
+                if (tt >= t1) break;
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = (float)v[u][e] * sc[e] + sh[e];
+                    if (a.silu) y = l2d_silu(y);
+                    o[e] = (h16)y;
+                }
+                l2d_st8(a.out + ((long long)b * a.T + tt) * C + vc * 8, o);
+            }
         }
     }
 }
@@ -174,8 +192,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16 *__restrict__ 
     if (row >= rows) return;
     const int nvc = C / 8;
     constexpr int MAXV = 4;  // C <= 2048
-    h16x8 v[MAXV];
+    h16x8 v[MAXV], gmv[MAXV], btv[MAXV];
     float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {      // all loads of the row AND its affine parameters go out before the first reduction
+        int vc = lane + 64 * j;
+        if (vc < nvc) { gmv[j] = l2d_ld8(gamma + vc * 8); btv[j] = l2d_ld8(beta + vc * 8); }
+    }
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         int vc = lane + 64 * j;
@@ -200,7 +223,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const h16 *__restrict__ 
     for (int j = 0; j < MAXV; ++j) {
         int vc = lane + 64 * j;
         if (vc < nvc) {
-            h16x8 gm = l2d_ld8(gamma + vc * 8), bt = l2d_ld8(beta + vc * 8), o;
+            const h16x8 gm = gmv[j], bt = btv[j];
+            h16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[j][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
             l2d_st8(out + (long long)row * ldo + vc * 8, o);

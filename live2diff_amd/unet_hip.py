@@ -313,7 +313,7 @@ class HipStreamingUNet:
         def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
             T = x.H * x.W
             C2 = x2.C if x2 is not None else 0
-            nchunk = max(1, min(128, T // 16))
+            nchunk = max(1, min(int(os.environ.get("L2D_GN_NCHUNK", "64")), T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
             out = new_act(x.C + C2, x.H, x.W)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
