@@ -312,6 +312,43 @@ def test_tattn_stream(L, C, T, Lw, S, N, variant):
     assert torch.equal(cache.cpu(), cache_ref.half()), "cache contents differ from the reference update"
 
 
+def test_tattn_stream_slot_permutation_full_size(L):
+    """BASELINE size of the largest KV-cache launch (N=2, T=4096, C=320, L=16; 168 MB cache), no oracle: softmax
+    attention over the L slots does not care about slot ORDER, so permuting the cache slots together with pe_idx, the
+    bias row and update_idx leaves the output unchanged (fp32 summation order only) and writes the new row to the
+    permuted slot."""
+    N, T, C, Lw = 2, 4096, 320, 16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV, dtype=torch.float16)
+    qkv, cache = rn(N * T, 3 * C), rn(N, 2, T, Lw, C)
+    tabs = [rn(24, C) * 0.5 for _ in range(3)]
+    pe_idx = torch.stack([torch.randperm(Lw, generator=torch.Generator().manual_seed(n)) for n in range(N)]).to(DEV)
+    upd = torch.tensor([9, 13], device=DEV)
+    bias = torch.zeros(N, Lw, dtype=torch.float16, device=DEV)
+    bias[1, 14:] = float("-inf")                                   # row 1: two masked slots
+    perm = torch.randperm(Lw, generator=torch.Generator().manual_seed(99)).to(DEV)   # new slot j holds old slot perm[j]
+    inv = torch.argsort(perm)
+    outs, caches = [], []
+    for permuted in (False, True):
+        c = cache.clone()
+        p_, b_, u_ = pe_idx, bias, upd
+        if permuted:
+            c = c[:, :, :, perm].contiguous()
+            p_, b_, u_ = pe_idx[:, perm].contiguous(), bias[:, perm].contiguous(), inv[upd]
+        out = torch.empty(N * T, C, dtype=torch.float16, device=DEV)
+        L.run(L.tattn_stream(qkv, c, tabs[0], tabs[1], tabs[2], p_, u_, b_, out, N=N, T=T, C=C, L=Lw, H=8))
+        torch.cuda.synchronize()
+        outs.append(out.float())
+        caches.append(c[:, :, :, inv].contiguous() if permuted else c)
+    assert torch.isfinite(outs[0]).all()
+    e = relerr(outs[1], outs[0])
+    assert e <= 1e-3, e                                            # fp16 output rounding of differently ordered fp32 sums
+    assert torch.equal(caches[0], caches[1]), "the new row must land in the permuted slot, nothing else may change"
+    k_new = qkv.view(N, T, 3 * C)[:, :, C:2 * C]
+    for n in range(N):
+        assert torch.equal(caches[0][n, 0, :, int(upd[n])], k_new[n])
+
+
 def test_tattn_stream_golden(L, golden):
     """directly against the fixture captured from the reference's StreamTemporalAttention (incl. projections
     done on the host in fp32 -> the kernel sees fp16-rounded q,k,v)."""
