@@ -5,7 +5,7 @@
 // 232-233,243,249; attention.py:57,102; motion_module.py:181,273; unet_depth_streaming.py:620-621).
 // It reads up to two inputs as one virtual channel-concat [x1 | x2], so the skip-connection torch.cat
 // of the up blocks (unet_blocks_streaming.py:683,814) is never materialised.
-//   pass 1 (gn_stats): per-(b, pixel-chunk) partial sum / sum-of-squares for each of the G groups
+//   pass 1 (gn_stats): per-(b, pixel-chunk) partial sum / sum-of-squares for each of the G groups (fixed summation order)
 //   pass 2 (gn_apply): deterministic reduction of the partials, then y = (x-mean)*rstd*gamma+beta (-> SiLU)
 // LayerNorm replaces nn.LayerNorm (attention.py:182,199,205; motion_module.py:355,361): one wave per row.
 #include "common.h"
@@ -27,52 +27,65 @@ __device__ __forceinline__ h16x8 gn_load(const GNArgs &a, long long pix, int vc)
 }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
-    __shared__ float s_sum[64], s_sq[64];
+    // Deterministic: per-thread channel sums go to LDS and thread g adds up group g's entries in a fixed order (no
+    // float atomics anywhere), so a frame is bit-repeatable and a hipGraph replay equals the direct launches exactly.
+    __shared__ float s_part[256][17];              // [thread][8 sums | 8 sums of squares] (+1: bank spread)
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int per = (a.T + a.nchunk - 1) / a.nchunk;
     const int t0 = chunk * per, t1 = min(a.T, t0 + per);
-    if (tid < 64) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-    __syncthreads();
     const int cols = min(nvc, 256), PR = 256 / cols;
     const int prow = tid / cols, vcl = tid - prow * cols;
+    float gs = 0.f, gq = 0.f;                      // partial sums of group tid/8 (8 threads per group), over all passes
     for (int cb = 0; cb < nvc; cb += cols) {
-        int vc = cb + vcl;
-        if (prow >= PR || vc >= nvc) continue;
+        const int vc = cb + vcl;
+        const bool active = prow < PR && vc < nvc;
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-        // 4 rows per trip, loads first: the loop is one dependent HBM/L2 round trip per iteration otherwise
-        for (int t = t0 + prow; t < t1; t += 4 * PR) {
-            h16x8 v[4];
+        if (active) {
+            // 4 rows per trip, loads first: the loop is one dependent HBM/L2 round trip per iteration otherwise
+            for (int t = t0 + prow; t < t1; t += 4 * PR) {
+                h16x8 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int tt = t + u * PR;
-                v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = t + u * PR;
+                    v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float f = (float)v[u][e]; s[e] += f; q[e] += f * f; }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = (float)v[u][e]; s[e] += f; q[e] += f * f; }
         }
-        // fold the 8 channels into their groups (runs of equal group id), then LDS atomics
-        int g_prev = (vc * 8) / cpg;
-        float rs = 0.f, rq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int g = (vc * 8 + e) / cpg;
-            if (g != g_prev) { atomicAdd(&s_sum[g_prev], rs); atomicAdd(&s_sq[g_prev], rq); rs = 0.f; rq = 0.f; g_prev = g; }
-            rs += s[e]; rq += q[e];
+        for (int e = 0; e < 8; ++e) { s_part[tid][e] = s[e]; s_part[tid][8 + e] = q[e]; }
+        __syncthreads();
+        {
+            // 8 threads per group (G <= 32): thread (g, j) adds the group's (channel, pixel-row) entries k = j, j+8, ...
+            // of this pass: channels [max(g*cpg, cb*8), min((g+1)*cpg, (cb+cols)*8, C)) x PR pixel rows
+            const int g = tid >> 3, j = tid & 7;
+            if (g < a.G) {
+                const int c0 = max(g * cpg, cb * 8), c1 = min(min((g + 1) * cpg, (cb + cols) * 8), C);
+                const int n = max(c1 - c0, 0) * PR;
+                for (int k = j; k < n; k += 8) {
+                    const int c = c0 + k / PR, pr = k - (k / PR) * PR;
+                    const int row = pr * cols + (c >> 3) - cb, e = c & 7;
+                    gs += s_part[row][e];
+                    gq += s_part[row][8 + e];
+                }
+            }
         }
-        atomicAdd(&s_sum[g_prev], rs);
-        atomicAdd(&s_sq[g_prev], rq);
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < a.G) {
-        float *dst = a.partial + (((long long)b * a.nchunk + chunk) * a.G + tid) * 2;
-        dst[0] = s_sum[tid];
-        dst[1] = s_sq[tid];
+    // fixed-order combine of the 8 partials of each group (lanes 8g .. 8g+7 of one wave)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+    if ((tid & 7) == 0 && (tid >> 3) < a.G) {
+        float *dst = a.partial + (((long long)b * a.nchunk + chunk) * a.G + (tid >> 3)) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
     }
 }
 
@@ -148,7 +161,7 @@ static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
     a.B = op->i[0]; a.T = op->i[1]; a.C1 = op->i[2]; a.C2 = op->i[3]; a.ld1 = op->i[4]; a.ld2 = op->i[5];
     a.G = op->i[6]; a.nchunk = op->i[7]; a.silu = op->i[8]; a.eps = op->f[0];
     int C = a.C1 + a.C2;
-    if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 64 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
+    if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 32 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
         (a.C2 > 0 && !a.x2) || a.nchunk <= 0 || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
         (apply && (!a.gamma || !a.beta || !a.out))) {
         l2d_set_error("groupnorm(tag %d): invalid arguments (B=%d T=%d C1=%d C2=%d G=%d nchunk=%d)", op->tag, a.B, a.T,

@@ -209,10 +209,8 @@ def test_cfg2_cache_update_is_exactly_one_slot(cfg2_unet):
 
 
 def test_cfg2_repeatable_and_graph_replay(cfg2_unet):
-    """Same inputs, same caches -> same output up to the one order-dependent sum in the plan (GroupNorm statistics use
-    LDS float atomics): the last-bit differences flip fp16 roundings downstream, and the randomly initialised 1.28 B
-    network amplifies them to ~2e-3 rel-L2 by the output -- bounded here at 5e-3 / cosine 0.9999, well inside the 1e-2
-    parity tolerance.  A hipGraph replay of the plan gives what the direct launches give, to the same bound."""
+    """Every reduction in the plan has a fixed order (split-K partials, GroupNorm partials, score exchange), so the same
+    inputs and caches give the same output BIT FOR BIT, and a hipGraph replay of the plan equals the direct launches."""
     from live2diff_amd.unet_hip import HipStreamingUNet
     unet, kv, i = cfg2_unet
     before = [c.clone() for c in kv]
@@ -220,14 +218,14 @@ def test_cfg2_repeatable_and_graph_replay(cfg2_unet):
     for c, b in zip(kv, before):
         c.copy_(b)
     b_ = _step(unet, kv, i)
-    assert rel(b_, a) <= 5e-3 and cos(b_, a) >= 0.9999, (rel(b_, a), cos(b_, a))
+    assert torch.equal(b_, a), rel(b_, a)
     for c, b in zip(kv, before):
         c.copy_(b)
     g = HipStreamingUNet.__new__(HipStreamingUNet)
     g.__dict__.update(unet.__dict__)
     g.use_graph, g._plans, g._graph = True, {}, {}
     c_ = _step(g, kv, i)
-    assert rel(c_, a) <= 5e-3 and cos(c_, a) >= 0.9999, (rel(c_, a), cos(c_, a))
+    assert torch.equal(c_, a), rel(c_, a)
     for c, b in zip(kv, before):
         c.copy_(b)
 
@@ -241,6 +239,6 @@ def test_cfg2_stream_batch_rows_are_independent(cfg2_unet):
     kv2 = [b.flip(0).contiguous() for b in before]
     j = {k: (v.flip(0).contiguous() if v.dim() >= 1 and v.shape[0] == 2 else v) for k, v in i.items()}
     b_ = _step(unet, kv2, j)
-    assert rel(b_.flip(0), a) <= 5e-3 and cos(b_.flip(0), a) >= 0.9999, rel(b_.flip(0), a)   # (same bound as repeatability)
+    assert torch.equal(b_.flip(0), a), rel(b_.flip(0), a)      # same tiles, same order: bit-identical
     for c, b in zip(kv, before):
         c.copy_(b)
