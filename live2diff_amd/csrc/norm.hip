@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
         const int g = tid & 63, part = tid >> 6;
         float s = 0.f, q = 0.f;
         if (g < a.G) {
-            for (int ch = part; ch < a.nchunk; ch += 4) {
-                const float *src = a.partial + (((long long)b * a.nchunk + ch) * a.G + g) * 2;
-                s += src[0]; q += src[1];
+            const float2 *src = reinterpret_cast<const float2 *>(a.partial) + (long long)b * a.nchunk * a.G + g;
+#pragma unroll 8
+            for (int ch = part; ch < a.nchunk; ch += 4) {      // unrolled: the partial loads go out together
+                const float2 v = src[(long long)ch * a.G];
+                s += v.x; q += v.y;
             }
         }
         s_part[part][g][0] = s; s_part[part][g][1] = q;
