@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
     const long long z = blockIdx.z;
     const float *wsp = a.ws + (long long)z * S * a.M * NoutP + (long long)m * NoutP + n;
     f32x4 v = *reinterpret_cast<const f32x4 *>(wsp);
-    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + (long long)s * a.M * NoutP);
+    const long long slab = (long long)a.M * NoutP;
+#pragma unroll 8
+    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + s * slab);   // (unrolled: loads in flight together; same order)
     igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
 }
 
