@@ -93,6 +93,18 @@ enum {
  * L2D_OP_LCM_STEP   x0 = c_out*(x - beta*eps)/alpha + c_skip*x  (reference pipeline :387-401)
  *   p0 x p1 eps p2 scal float [N][4]={alpha,beta,c_skip,c_out} p3 x0 ; i0 N i1 per_sample_elems
  * L2D_OP_COPY       p0 src p1 dst ; l0 bytes   (device-to-device, on the stream)
+ *
+ * Per-frame pipeline glue on the device (stream_glue.hip):
+ * L2D_OP_RING_UPDATE  update_attn_bias (reference pipeline_stream_animation_depth.py:416-438), in place:
+ *   p0 bias [N][L] half (0 / -inf) p1 pe_idx [N][L] int64 p2 update_idx [N] int64 p3 frame counter uint64* or 0
+ *   (incremented by one); i0 N i1 L i2 sink (= warm-up frames)
+ * L2D_OP_STREAM_SHIFT scheduler_step_batch + stream-batch shift register (reference :387-401, :590-601):
+ *   p0 x_t [N][per] half (in: the batch the UNet just saw; out: rows 1..N-1 = next frame's buffer)
+ *   p1 eps [N][per] half (UNet output) p2 scal [N][4] float {alpha, beta, c_skip, c_out} p3 noise [N-1][per] half or 0
+ *   p4 x0_out [per] half (x0 prediction of the last row) p5 depth [N][per] half or 0 (row i+1 <- row i)
+ *   i0 N (<= 8) i1 per (elements per row)
+ * L2D_OP_RANDN      p0 out [n] half, standard normal (Philox4x32-10 + Box-Muller) p1 frame counter uint64* or 0
+ *   l0 n l1 seed l2 offset (in Philox blocks of 4); element i = normal i%4 of block offset + frame*ceil(n/4) + i/4
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -108,6 +120,9 @@ enum {
     L2D_OP_NHWC_TO_NCHW = 11,
     L2D_OP_LCM_STEP = 12,
     L2D_OP_COPY = 13,
+    L2D_OP_RING_UPDATE = 14,
+    L2D_OP_STREAM_SHIFT = 15,
+    L2D_OP_RANDN = 16,
 };
 
 typedef struct l2d_op {

@@ -42,6 +42,9 @@ static int run_one(const l2d_op *op, hipStream_t s) {
         case L2D_OP_NCHW_TO_NHWC: return l2d_launch_nchw_to_nhwc(op, s);
         case L2D_OP_NHWC_TO_NCHW: return l2d_launch_nhwc_to_nchw(op, s);
         case L2D_OP_LCM_STEP: return l2d_launch_lcm_step(op, s);
+        case L2D_OP_RING_UPDATE: return l2d_launch_ring_update(op, s);
+        case L2D_OP_STREAM_SHIFT: return l2d_launch_stream_shift(op, s);
+        case L2D_OP_RANDN: return l2d_launch_randn(op, s);
         case L2D_OP_COPY: {
             if (!op->p[0] || !op->p[1] || op->l[0] <= 0) {
                 l2d_set_error("copy(tag %d): invalid arguments", op->tag);

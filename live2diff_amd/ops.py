@@ -275,6 +275,38 @@ def lcm_step(x, eps, scal, x0, *, N, per):
     return op, (x, eps, scal, x0)
 
 
+def ring_update(bias, pe_idx, update_idx, *, N, L, sink, frame_ctr=None):
+    """update_attn_bias on the device, in place (reference pipeline_stream_animation_depth.py:416-438)."""
+    assert bias.dtype == torch.float16 and pe_idx.dtype == torch.int64 and update_idx.dtype == torch.int64
+    assert frame_ctr is None or (frame_ctr.dtype == torch.int64 and frame_ctr.numel() >= 1)
+    op = L2dOp()
+    op.kind = _lib.OP_RING_UPDATE
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(bias), _ptr(pe_idx), _ptr(update_idx), _ptr(frame_ctr)
+    op.i[0], op.i[1], op.i[2] = N, L, sink
+    return op, (bias, pe_idx, update_idx, frame_ctr)
+
+
+def stream_shift(x_t, eps, scal, x0_out, *, N, per, noise=None, depth=None):
+    """LCM step of the N rows + stream-batch shift register, in place on x_t / depth (reference :387-401, :590-601)."""
+    assert scal.dtype == torch.float32 and scal.numel() >= 4 * N
+    assert noise is None or noise.numel() >= (N - 1) * per
+    op = L2dOp()
+    op.kind = _lib.OP_STREAM_SHIFT
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(x_t)), _ptr(_h(eps)), _ptr(scal), _ptr(noise)
+    op.p[4], op.p[5] = _ptr(_h(x0_out)), _ptr(depth)
+    op.i[0], op.i[1] = N, per
+    return op, (x_t, eps, scal, noise, x0_out, depth)
+
+
+def randn(out, *, seed: int, offset: int = 0, frame_ctr=None):
+    """Standard-normal fill (Philox4x32-10 + Box-Muller); with `frame_ctr` the stream position advances per frame."""
+    op = L2dOp()
+    op.kind = _lib.OP_RANDN
+    op.p[0], op.p[1] = _ptr(_h(out)), _ptr(frame_ctr)
+    op.l[0], op.l[1], op.l[2] = out.numel(), int(seed), int(offset)
+    return op, (out, frame_ctr)
+
+
 def copy(src, dst, nbytes):
     op = L2dOp()
     op.kind = _lib.OP_COPY

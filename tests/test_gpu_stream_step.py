@@ -1,0 +1,180 @@
+"""-m gpu: the device-side per-frame pipeline glue (csrc/stream_glue.hip, stream_step_hip.py).
+
+Integer / byte work (the ring-buffer state machine) is checked BIT-EXACTLY against the 40-frame trace captured from
+the reference (tests/golden/state_machine.npz) and against the host restatement for the other window sizes; the LCM
+step + shift register is checked bit-exactly against the reference-pinned host tensor expression evaluated in fp16
+(same rounding points); the noise generator has no reference stream to match (torch.randn is backend specific), so it
+is checked for reproducibility and for its distribution.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_ring_update_matches_reference_trace(golden, n):
+    from live2diff_amd import ops
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init
+    g = golden("state_machine")
+    b, p, u = ring_buffer_init(n)
+    bd, pd, ud = b.half().to(DEV), p.to(DEV), u.to(DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for f in range(41):
+        assert torch.equal(bd.float().cpu(), torch.from_numpy(g[f"bias_n{n}"][f])), f
+        assert torch.equal(pd.cpu(), torch.from_numpy(g[f"pe_idx_n{n}"][f])), f
+        assert torch.equal(ud.cpu(), torch.from_numpy(g[f"update_idx_n{n}"][f])), f
+        ops.run(ops.ring_update(bd, pd, ud, N=n, L=16, sink=8, frame_ctr=ctr))
+        torch.cuda.synchronize()
+    assert int(ctr) == 41
+
+
+@pytest.mark.parametrize("n,L,S", [(1, 12, 4), (2, 24, 8), (2, 40, 8), (4, 16, 8), (8, 16, 8)])
+def test_ring_update_other_windows_match_host(n, L, S):
+    from live2diff_amd import ops
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    b, p, u = ring_buffer_init(n, L, S)
+    bd, pd, ud = b.half().to(DEV), p.to(DEV), u.to(DEV)
+    for f in range(3 * L):
+        ring_buffer_update(b, p, u, L, S)
+        ops.run(ops.ring_update(bd, pd, ud, N=n, L=L, sink=S))
+        torch.cuda.synchronize()
+        assert torch.equal(bd.float().cpu(), b) and torch.equal(pd.cpu(), p) and torch.equal(ud.cpu(), u), f
+
+
+@pytest.mark.parametrize("N,noise_on,depth_on", [(2, True, True), (4, True, True), (3, False, True), (1, True, False), (2, True, False)])
+def test_stream_shift_bit_exact(golden, N, noise_on, depth_on):
+    """x0 / next-buffer arithmetic with the reference's fp16 rounding points: bit-identical to the reference-pinned host
+    expressions (scheduler_step_batch + the buffer update of predict_x0_batch) evaluated with fp16 tensors."""
+    from live2diff_amd import ops
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth as S
+    from live2diff_amd.scheduler import LCMSchedule
+    sch = LCMSchedule()
+    sch.set_timesteps(50)
+    ts = [399, 299, 199, 99][:N]
+    al = torch.tensor([float(sch.alphas_cumprod[t]) ** 0.5 for t in ts])
+    be = torch.tensor([(1 - float(sch.alphas_cumprod[t])) ** 0.5 for t in ts])
+    cs, co = zip(*[sch.get_scalings_for_boundary_condition_discrete(t) for t in ts])
+    shp = (N, 1, 1, 1, 1)
+    fake = S.__new__(S)
+    to = dict(device=DEV, dtype=torch.float16)
+    fake.alpha_prod_t_sqrt, fake.beta_prod_t_sqrt = al.view(shp).to(**to), be.view(shp).to(**to)
+    fake.c_skip = torch.tensor([float(c) for c in cs]).view(shp).to(**to)
+    fake.c_out = torch.tensor([float(c) for c in co]).view(shp).to(**to)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    h = w = 16
+    per = 4 * h * w
+    x = torch.randn(N, 4, 1, h, w, generator=g, **to)
+    eps = torch.randn(N, 4, 1, h, w, generator=g, **to)
+    nz = torch.randn(max(N - 1, 1), 4, 1, h, w, generator=g, **to)
+    dep = torch.randn(N, 4, 1, h, w, generator=g, **to)
+    # reference-pinned host expressions (fp16 tensors on the device)
+    x0 = S.scheduler_step_batch(fake, eps, x)
+    want_out = x0[-1]
+    if N > 1:
+        want_buf = fake.alpha_prod_t_sqrt[1:] * x0[:-1]
+        if noise_on:
+            want_buf = want_buf + fake.beta_prod_t_sqrt[1:] * nz[: N - 1]
+    scal = torch.stack([fake.alpha_prod_t_sqrt.reshape(-1).float(), fake.beta_prod_t_sqrt.reshape(-1).float(),
+                        fake.c_skip.reshape(-1).float(), fake.c_out.reshape(-1).float()], 1).contiguous()
+    xd, dd = x.clone(), dep.clone()
+    out = torch.zeros(per, **to)
+    ops.run(ops.stream_shift(xd, eps, scal, out, N=N, per=per, noise=(nz if noise_on else None), depth=(dd if depth_on else None)))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view_as(want_out), want_out)
+    assert torch.equal(xd[0], x[0])                       # row 0 is the caller's (next frame's latent goes there)
+    if N > 1:
+        assert torch.equal(xd[1:], want_buf)
+        if depth_on:
+            assert torch.equal(dd[1:], dep[:-1]) and torch.equal(dd[0], dep[0])
+
+
+def test_randn_reproducible_and_normal():
+    from live2diff_amd import ops
+    n = 1 << 20
+    a = torch.empty(n, dtype=torch.float16, device=DEV)
+    b = torch.empty(n, dtype=torch.float16, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.run(ops.randn(a, seed=7, frame_ctr=ctr))
+    ops.run(ops.randn(b, seed=7, frame_ctr=ctr))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                              # same (seed, stream position) -> same tensor
+    ctr += 1
+    ops.run(ops.randn(b, seed=7, frame_ctr=ctr))
+    c = torch.empty(n - 3, dtype=torch.float16, device=DEV)
+    ops.run(ops.randn(c, seed=8))
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b) and abs(float((a.float() * b.float()).mean())) < 5e-3      # next frame: fresh, uncorrelated
+    for t in (a, b, c):
+        f = t.double().cpu()
+        assert torch.isfinite(f).all()
+        m, v = f.mean().item(), f.var().item()
+        k = ((f - m) ** 4).mean().item() / v ** 2
+        assert abs(m) < 5e-3 and abs(v - 1) < 1e-2 and abs(k - 3) < 5e-2, (m, v, k)
+        assert 0.30 < (f.abs() > 1).double().mean().item() < 0.335                          # P(|z| > 1) = 0.3173
+
+
+@pytest.mark.parametrize("N,use_graph", [(2, False), (3, True)])
+def test_device_step_equals_host_pipeline(golden, N, use_graph):
+    """HipStreamStep (everything between two frames on the device, one static plan / hipGraph) against the host-driven
+    path -- UNet boundary call + torch tensor expressions + host ring buffer -- with the re-noising tensor injected
+    into both: identical x0 outputs, x_t buffers, ring-buffer states and KV caches over warm ring-buffer wrap-around."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth as S
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    from live2diff_amd.scheduler import LCMSchedule
+    from live2diff_amd.stream_step_hip import HipStreamStep
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    h = w = 16
+    sd = {k: v.to(DEV) for k, v in random_state_dict(cfg, dtype=torch.float16).items()}
+    ua, ub = HipStreamingUNet(sd, cfg, h, w, N), HipStreamingUNet(sd, cfg, h, w, N)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    to = dict(device=DEV, dtype=torch.float16)
+    rn = lambda *s: torch.randn(*s, generator=g, **to)
+    kva, kvb = ua.prepare_cache(N), ub.prepare_cache(N)
+    for a, b in zip(kva, kvb):
+        a.normal_(generator=g)
+        b.copy_(a)
+    sch = LCMSchedule()
+    sch.set_timesteps(50)
+    ts_list = [399, 299, 199][:N]
+    shp = (N, 1, 1, 1, 1)
+    fake = S.__new__(S)
+    fake.alpha_prod_t_sqrt = torch.tensor([float(sch.alphas_cumprod[t]) ** 0.5 for t in ts_list]).view(shp).to(**to)
+    fake.beta_prod_t_sqrt = torch.tensor([(1 - float(sch.alphas_cumprod[t])) ** 0.5 for t in ts_list]).view(shp).to(**to)
+    sc = [sch.get_scalings_for_boundary_condition_discrete(t) for t in ts_list]
+    fake.c_skip = torch.tensor([float(c[0]) for c in sc]).view(shp).to(**to)
+    fake.c_out = torch.tensor([float(c[1]) for c in sc]).view(shp).to(**to)
+    ts = torch.tensor(ts_list, device=DEV)
+    enc = rn(N, 77, cfg.cross_attention_dim)
+    xbuf, dbuf = rn(N - 1, 4, 1, h, w), rn(N - 1, 4, 1, h, w)
+    step = HipStreamStep(ub, kvb, ts, enc, fake.alpha_prod_t_sqrt, fake.beta_prod_t_sqrt, fake.c_skip, fake.c_out,
+                         inject_noise=True, use_graph=use_graph)
+    step.load_buffers(xbuf, dbuf)
+    rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)
+    for f in range(2 * cfg.window_size + 3):
+        x_new, d_new = rn(1, 4, 1, h, w), rn(1, 4, 1, h, w)
+        nz = rn(N - 1, 4, 1, h, w)
+        # host-driven path (predict_x0_batch, reference :573-623)
+        xt, dt = torch.cat((x_new, xbuf), 0), torch.cat((d_new, dbuf), 0)
+        o = ua(xt, ts, encoder_hidden_states=enc, temporal_attention_mask=rb[0].half().to(DEV), depth_sample=dt, kv_cache=kva,
+               pe_idx=rb[1].to(DEV), update_idx=rb[2].to(DEV))
+        x0 = S.scheduler_step_batch(fake, o["sample"], xt)
+        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
+        want_out = x0[-1:].clone()
+        xbuf = fake.alpha_prod_t_sqrt[1:] * x0[:-1] + fake.beta_prod_t_sqrt[1:] * nz
+        dbuf = dt[:-1].clone()
+        # device path
+        step.noise.copy_(nz.reshape(-1))
+        got = step.step(x_new, d_new)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want_out), f
+        assert torch.equal(step.x_t_latent_buffer, xbuf), f
+        assert torch.equal(step.attn_bias.float().cpu(), rb[0]) and torch.equal(step.pe_idx.cpu(), rb[1]), f
+        assert torch.equal(step.update_idx.cpu(), rb[2]), f
+    for a, b in zip(kva, kvb):
+        assert torch.equal(a, b)

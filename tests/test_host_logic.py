@@ -159,3 +159,36 @@ def test_plan_validates_sd15_shapes(dry_run):
     st.pl.run(stream=0)
     assert st.n_ops > 600
     assert abs(unet.weight_bytes() / 1e9 - 2.6) < 0.2
+
+
+def test_device_step_plan_validates_without_gpu(dry_run):
+    """HipStreamStep (UNet plan + randn + stream_shift + ring_update as one op list) built on CPU
+    tensors; every op passes the C library's validation, and malformed glue ops are refused."""
+    from live2diff_amd import _lib, ops
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.stream_step_hip import HipStreamStep
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    N = 3
+    unet = HipStreamingUNet(random_state_dict(cfg, dtype=torch.float16), cfg, 16, 16, N, device="cpu")
+    kv = unet.prepare_cache(N)
+    one = torch.ones(N, 1, 1, 1, 1, dtype=torch.float16)
+    step = HipStreamStep(unet, kv, torch.tensor([399, 299, 199]), torch.zeros(N, 77, 64, dtype=torch.float16), one, one, one, one)
+    step.pl.run(stream=0)                    # validate-only
+    kinds = [step.pl[j].kind for j in range(len(step.pl))]
+    assert kinds[-3:] == [_lib.OP_RANDN, _lib.OP_STREAM_SHIFT, _lib.OP_RING_UPDATE]
+    assert len(step.pl) == len(step.st.pl) + 3
+
+    def validate(opk):
+        pl = _lib.OpList()
+        pl.append(*opk)
+        pl.run(stream=0)
+
+    x = torch.zeros(9, 64, dtype=torch.float16)
+    with pytest.raises(_lib.L2DError):       # more rows than the shift register supports
+        validate(ops.stream_shift(x, x, torch.zeros(9, 4), x[0], N=9, per=64))
+    b, p, u = torch.zeros(2, 16, dtype=torch.float16), torch.zeros(2, 16, dtype=torch.int64), torch.zeros(2, dtype=torch.int64)
+    with pytest.raises(_lib.L2DError):       # sink must lie inside the window
+        validate(ops.ring_update(b, p, u, N=2, L=16, sink=16))
+    validate(ops.ring_update(b, p, u, N=2, L=16, sink=8))
