@@ -333,9 +333,30 @@ class StreamAnimateDiffusionDepth:
         dn = F.interpolate(dn, (h, w), mode="bilinear", align_corners=False)
         return retrieve_latents(self.vae.encode(dn.to(dtype=self.vae.dtype)), self.generator) * self.vae.config.scaling_factor
 
+    def enable_device_step(self, use_graph: bool = False, seed: int = 0):
+        """Opt in to the device-side frame step (stream_step_hip.HipStreamStep): after `prepare`,
+        everything `predict_x0_batch` does around the UNet (batch assembly, LCM step, buffer shift, re-noising,
+        ring-buffer update) runs as ops of the UNet's own static plan.  Needs the HIP UNet backend; frame_bff_size 1."""
+        from .stream_step_hip import HipStreamStep
+        from .unet_hip import HipStreamingUNet
+        if not isinstance(self.unet, HipStreamingUNet) or self.frame_bff_size != 1:
+            raise ValueError("enable_device_step needs the HipStreamingUNet backend and frame_bff_size == 1")
+        self._device_step = HipStreamStep(self.unet, self.kv_cache_list, self.sub_timesteps_tensor, self.prompt_embeds,
+                                          self.alpha_prod_t_sqrt, self.beta_prod_t_sqrt, self.c_skip, self.c_out,
+                                          do_add_noise=self.do_add_noise, seed=seed, use_graph=use_graph)
+        self._device_step.load_buffers(self.x_t_latent_buffer, self.depth_latent_buffer)
+        return self._device_step
+
     def predict_x0_batch(self, x_t_latent, depth_latent, noise: Optional[torch.Tensor] = None):
         """reference :573-623 (stream-batch shift register). `noise` lets tests inject the re-noising tensor."""
         n = self.denoising_steps_num
+        ds = getattr(self, "_device_step", None)
+        if ds is not None and noise is None:
+            x_0_pred_out = ds.step(x_t_latent, depth_latent)
+            self.attn_bias, self.pe_idx, self.update_idx = ds.attn_bias, ds.pe_idx, ds.update_idx
+            if n > 1:
+                self.x_t_latent_buffer = ds.x_t_latent_buffer
+            return x_0_pred_out
         if n > 1:
             x_t_latent = torch.cat((x_t_latent, self.x_t_latent_buffer), dim=0)
             depth_latent = torch.cat((depth_latent, self.depth_latent_buffer), dim=0)

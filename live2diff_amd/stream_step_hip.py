@@ -64,6 +64,7 @@ class HipStreamStep:
                                    frame_ctr=self.frame_ctr))
         self.pl = pl
         self._graph = None
+        self._warm = False
 
     # ---- state the caller owns in the reference (x_t_latent_buffer / depth_latent_buffer, set by `prepare`)
     def load_buffers(self, x_t_latent_buffer: Optional[torch.Tensor], depth_latent_buffer: Optional[torch.Tensor]):
@@ -94,10 +95,15 @@ class HipStreamStep:
         c = self.unet.cfg.in_channels
         self.st.in_sample[0].copy_(x_t_latent.reshape(c, -1))
         self.st.in_depth[0].copy_(depth_latent.reshape(c, -1))
-        if self.use_graph:
-            if self._graph is None:
-                self._graph = _lib.Graph(self.pl)
+        if self.use_graph and self._warm:
+            if self._graph is None:             # capture on a side stream (the legacy default stream cannot be captured)
+                side = torch.cuda.Stream(device=self.unet.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._graph = _lib.Graph(self.pl, stream=int(side.cuda_stream))
+                torch.cuda.current_stream().wait_stream(side)
             self._graph.launch()
         else:
-            self.pl.run()
+            self.pl.run()           # (the first frame always runs directly: one-time kernel attribute / device queries
+            self._warm = True       # of the launchers are not allowed inside a stream capture)
         return self.x0_out.view(1, c, 1, self.unet.h, self.unet.w)

@@ -178,3 +178,66 @@ def test_device_step_equals_host_pipeline(golden, N, use_graph):
         assert torch.equal(step.update_idx.cpu(), rb[2]), f
     for a, b in zip(kva, kvb):
         assert torch.equal(a, b)
+
+
+class _StubVAE:
+    """Caller-owned duck-typed VAE (reference swap point `stream.vae`, engine.py:71-109): 8x average-pool 'encoder' to 4
+    channels and nearest-upsample 'decoder' -- enough to drive the pipeline's per-frame path end to end."""
+    dtype = torch.float16
+
+    class config:
+        scaling_factor = 0.5
+
+    def encode(self, x):
+        lat = torch.nn.functional.avg_pool2d(x.float(), 8)
+        lat = torch.cat([lat, lat.mean(1, keepdim=True)], 1).to(torch.float16)      # 3 -> 4 channels
+        return type("Out", (), {"latents": lat})()
+
+    def decode(self, z, return_dict=False):
+        return (torch.nn.functional.interpolate(z[:, :3].float(), scale_factor=8, mode="nearest").to(torch.float16),)
+
+
+class _StubDepth:
+    dtype = torch.float16
+
+    def __call__(self, images):
+        return images.float().mean(1).to(torch.float16) + 1.0                          # [B,384,384]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipeline_frames_device_step_vs_host_path(golden, use_graph):
+    """StreamAnimateDiffusionDepth end to end on the HIP UNet (prepare = N warm-up passes, then frames through
+    __call__): the opt-in device-side step gives bit-identical frames to the host-driven predict_x0_batch
+    (do_add_noise=False: the two paths draw their re-noising tensors from different generators)."""
+    from types import SimpleNamespace
+
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    H = W = 128
+    sd = {k: v.to(DEV) for k, v in random_state_dict(cfg, dtype=torch.float16).items()}
+    g = torch.Generator().manual_seed(5)
+    warm = [torch.rand(3, H, W, generator=g) for _ in range(cfg.sink_size)]
+    frames = [torch.rand(1, 3, H, W, generator=g) for _ in range(2 * cfg.window_size)]
+    emb = torch.randn(1, 77, 64, generator=g)
+    outs = []
+    for device_step in (False, True):
+        pipe = SimpleNamespace(device=torch.device(DEV), vae_scale_factor=8, unet=HipStreamingUNet(sd, cfg, H // 8, W // 8, 2),
+                               vae=_StubVAE(), depth_model=_StubDepth(), scheduler=None)
+        s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=[30, 40], width=W, height=H, do_add_noise=False,
+                                        warmup_frames=cfg.sink_size, window_size=cfg.window_size)
+        s.prepare_cache(H, W, 2)
+        first = s.prepare(warm, prompt_embeds=emb, seed=3)
+        assert torch.isfinite(first).all()
+        if device_step:
+            s.enable_device_step(use_graph=use_graph)
+        res = [s(f.to(DEV)).clone() for f in frames]
+        assert all(torch.isfinite(r).all() for r in res)
+        outs.append((first, res, [c.clone() for c in s.kv_cache_list], s.update_idx.clone().cpu(), s.pe_idx.clone().cpu()))
+    (fa, ra, ka, ua, pa), (fb, rb_, kb, ub, pb) = outs
+    assert torch.equal(fa, fb)
+    for i, (a, b) in enumerate(zip(ra, rb_)):
+        assert torch.equal(a, b), i
+    assert all(torch.equal(a, b) for a, b in zip(ka, kb)) and torch.equal(ua, ub) and torch.equal(pa, pb)
