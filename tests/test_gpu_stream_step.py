@@ -224,6 +224,7 @@ def test_pipeline_frames_device_step_vs_host_path(golden, use_graph):
     emb = torch.randn(1, 77, 64, generator=g)
     outs = []
     for device_step in (False, True):
+        torch.manual_seed(0)        # `prepare` re-noises the warm-up latents from the global generator, like the reference (:337)
         pipe = SimpleNamespace(device=torch.device(DEV), vae_scale_factor=8, unet=HipStreamingUNet(sd, cfg, H // 8, W // 8, 2),
                                vae=_StubVAE(), depth_model=_StubDepth(), scheduler=None)
         s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=[30, 40], width=W, height=H, do_add_noise=False,
