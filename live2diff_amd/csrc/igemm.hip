@@ -13,24 +13,29 @@
 //     loads in the epilogue; for GEGLU the value and gate columns (interleaved by 16 at pack time) land
 //     in the same lane.
 //   * 256 threads = 4 waves (2x2), block tile TN x TM (128x128 or 64x64).
-//   * Operand staging is LDS-DMA: `global_load_lds_dwordx4` (16 B/lane, no VGPR round trip) into a ring of
-//     NS stages of BK K-elements (default BK = 64 x 2 stages: 64 KB for the 128x128 tile -> 2 blocks/CU, 32 KB
-//     for 64x64), counted `s_waitcnt vmcnt(N)` + raw `s_barrier` so the DMA queue is never drained inside the
-//     loop (one barrier per K step).  Round-1a's register-staged loop was latency bound (rocprof r1a); the
-//     on-GPU sweep (profiles/r1b_igemm_sweep.txt) showed the kernel is then insensitive to ring depth and bound
-//     by per-stage issue work, so BK = 64 (half the barriers / DMA instructions of BK = 32) is the default.
+//   * Operand staging is LDS-DMA: `global_load_lds_dwordx4` (16 B/lane, no VGPR round trip) into a ring of NS stages
+//     of BK K-elements, counted `s_waitcnt vmcnt((NS-2)*LPS)` + raw `s_barrier`: NS-1 stages stay in flight and the
+//     DMA queue is never drained inside the loop (one barrier per K step).  Pipeline shapes (op.i[23], launch_p):
+//     BK32 x 3/4/6, BK64 x 2/3/4/6, BK128 x 2/3.  Warm, isolated sweeps are insensitive to the depth; in the frame the
+//     weights arrive cold and the 64x64 tile wants BK64 x 3 (85.3 vs 79.9 frames/s with x2).  The per-shape choice of
+//     (tile, split-K, shape) is a table measured in the frame (live2diff_amd/igemm_tuned.json, tools/igemm_pick.py).
 //   * The LDS image of a DMA is lane-linear (wave-uniform base + 16*lane), so the bank swizzle is applied on
 //     the SOURCE side: a lane fetches logical 16-byte slot  pslot ^ swz(row)  of its row and the fragment
 //     reads apply the same XOR -> conflict-free ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0 in the PMC pass).
 //     Conv zero padding / ragged rows / channel tails read from a 16-byte zero page.
-//   * PMC (profiles/r1b_pmc.txt) showed ~12 VALU + 7 SALU instructions per MFMA, i.e. the loop was bound by
-//     the gather's address arithmetic, not by the matrix cores.  The gather is therefore reduced to one 64-bit
-//     add + select per row per stage: per-row element offsets and a 9-bit tap-validity mask are computed once,
+//   * PMC (profiles/r1b_pmc_ops.txt) showed ~12 VALU + 7 SALU instructions per MFMA in the first version, i.e. the loop
+//     was bound by the gather's address arithmetic, not by the matrix cores.  The gather is therefore reduced to one
+//     64-bit add + select per row per stage: per-row element offsets and a 9-bit tap-validity mask are computed once,
 //     the per-stage part (tap offset, channel offset) is wave-uniform scalar work.  Nearest-upsample convs and
 //     3x3 convs over a two-input concat use the generic (slower) gather.
 //   * Split-K (grid.y) for the low-resolution levels (M = 128..2048, K up to 23 040): fp32 partial tiles to a
-//     workspace, reduced by `igemm_splitk_epilogue` which applies the same fused epilogue.
-//   * XCD-aware block order: consecutive tiles (same token tile, neighbouring weight tiles) land on one XCD.
+//     workspace, reduced in a fixed order by `igemm_splitk_epilogue`, which applies the same fused epilogue.
+//   * XCD-aware block order: each XCD runs a contiguous tile range, token-tile major or (op.i[22] & 16) weight-tile
+//     major, whichever keeps the larger operand in ONE L2 (28.5 vs 43.6 MB of L2 fills per launch, frame average).
+//   * In-kernel timestamps (s_memtime) on the GEGLU GEMM M 8192 x N 2560 x K 320: a 128x128 block lives 25.8 k cycles,
+//     4.5 k before the loop (kernel arguments, descriptors, first DMA issue), 12.2 k in 10 K steps with three blocks
+//     sharing the CU, 9.0 k in the epilogue -- the K = 320..1280 linear layers of this UNet are bound by what surrounds
+//     the MFMA loop.
 #include "common.h"
 
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
