@@ -93,10 +93,11 @@ class _Act:
 
 
 class HipStreamingUNet:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: UNetConfig, height: int, width: int,
+    def __init__(self, state_dict, cfg: UNetConfig, height: int, width: int,
                  denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
                  tattn_variant: int = 0, text_len: int = 77):
-        """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names."""
+        """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names; it may also be the
+        path of a packed-weight file written by `save_packed`."""
         assert cfg.num_heads == 8 and cfg.temporal_heads == 8
         assert height % 8 == 0 and width % 8 == 0, "latent size must be divisible by 8 (3 down-samplings, T%4==0)"
         self.cfg, self.h, self.w, self.N = cfg, height, width, denoising_steps_num
@@ -111,7 +112,10 @@ class HipStreamingUNet:
         self.config = SimpleNamespace(in_channels=cfg.in_channels)      # read by the reference wrapper (:524)
         self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()   # raises unless a gfx950 is present
         self.mm_layout = motion_module_layout(cfg, height, width)
-        self._pack_weights(state_dict)
+        if isinstance(state_dict, (str, os.PathLike)):
+            self._load_packed(state_dict)          # a file written by save_packed(): skips the packing pass
+        else:
+            self._pack_weights(state_dict)
         self._plans = {}
         self._graph = {}
 
@@ -251,6 +255,52 @@ class HipStreamingUNet:
 
     def weight_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.W.values())
+
+    # ------------------------------------------------------------------ packed-weight cache
+    PACK_FORMAT = 1      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
+
+    def save_packed(self, path) -> None:
+        """Write the packed weights (what `_pack_weights` produced from the reference-keyed state dict: merged
+        DreamBooth / LoRA weights, permuted, fused and padded for the kernels, PE tables pre-projected) as one
+        safetensors file.  The analogue of the reference's TensorRT engine cache (wrapper.py:300-332, :505-560): a style
+        switch that was seen before skips the conversion.  Packed weights depend on the weights and on the window
+        length only -- not on resolution or on the number of denoising steps."""
+        import json
+
+        from safetensors.torch import save_file
+        meta = dict(format=str(self.PACK_FORMAT), abi=str(_lib.ABI_VERSION), window=str(self.cfg.window_size),
+                    block_out_channels=json.dumps(list(self.cfg.block_out_channels)),
+                    temb_offsets=json.dumps(self.temb_offsets), text_offsets=json.dumps(self.text_offsets),
+                    n_map_blocks=str(self.n_map_blocks))
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.W.items()}, str(path), metadata=meta)
+
+    def _load_packed(self, path) -> None:
+        import json
+
+        from safetensors import safe_open
+        with safe_open(str(path), framework="pt", device="cpu") as f:
+            meta = f.metadata() or {}
+            if int(meta.get("format", -1)) != self.PACK_FORMAT or int(meta.get("abi", -1)) != _lib.ABI_VERSION:
+                raise ValueError(f"{path}: packed-weight format {meta.get('format')} / ABI {meta.get('abi')} does not match "
+                                 f"this build ({self.PACK_FORMAT} / {_lib.ABI_VERSION}): re-pack from the state dict")
+            if int(meta["window"]) != self.cfg.window_size or json.loads(meta["block_out_channels"]) != list(self.cfg.block_out_channels):
+                raise ValueError(f"{path}: packed for window {meta['window']} / widths {meta['block_out_channels']}, "
+                                 f"this instance is window {self.cfg.window_size} / {list(self.cfg.block_out_channels)}")
+            self.W = {k: f.get_tensor(k).to(self.device) for k in f.keys()}
+        self.temb_offsets = {k: int(v) for k, v in json.loads(meta["temb_offsets"]).items()}
+        self.text_offsets = {k: int(v) for k, v in json.loads(meta["text_offsets"]).items()}
+        self.n_map_blocks = int(meta["n_map_blocks"])
+        self.temb_total = self.W["temb_all.w"].shape[0]
+        self.text_total, self.text_kp = self.W["text_k.w"].shape
+
+    @staticmethod
+    def packed_cache_name(model_name: str, few_step_model_type: str, window_size: int, lora_dict: Optional[dict] = None) -> str:
+        """File stem for a packed-weight cache entry, in the spirit of the reference's engine prefix
+        (wrapper.py:300-332) minus what packed weights do not depend on (steps, resolution, tiny-VAE)."""
+        stem = f"{model_name}--{few_step_model_type}--"
+        for k, v in (lora_dict or {}).items():
+            stem += f"{os.path.splitext(os.path.basename(str(k)))[0]}-{v}--"
+        return stem + f"L{window_size}--l2dpack{HipStreamingUNet.PACK_FORMAT}"
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, mode: str, kv_cache: List[torch.Tensor]):

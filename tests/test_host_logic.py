@@ -192,3 +192,23 @@ def test_device_step_plan_validates_without_gpu(dry_run):
     with pytest.raises(_lib.L2DError):       # sink must lie inside the window
         validate(ops.ring_update(b, p, u, N=2, L=16, sink=16))
     validate(ops.ring_update(b, p, u, N=2, L=16, sink=8))
+
+
+def test_packed_weight_cache_round_trip(dry_run, tmp_path):
+    """save_packed / load from path: identical packed tensors and layout tables, the plan built from
+    the cache file validates, and a file packed for another window or format is refused."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    a = HipStreamingUNet(random_state_dict(cfg, dtype=torch.float16), cfg, 16, 16, 2, device="cpu")
+    path = tmp_path / (HipStreamingUNet.packed_cache_name("sd15", "lcm", cfg.window_size, {"loras/style.safetensors": 0.8}) + ".safetensors")
+    assert path.name == f"sd15--lcm--style-0.8--L{cfg.window_size}--l2dpack1.safetensors"
+    a.save_packed(path)
+    b = HipStreamingUNet(path, cfg, 8, 24, 3, device="cpu")           # other resolution / step count: same packed weights
+    assert set(a.W) == set(b.W) and all(torch.equal(a.W[k], b.W[k]) and a.W[k].dtype == b.W[k].dtype for k in a.W)
+    assert a.temb_offsets == b.temb_offsets and a.text_offsets == b.text_offsets
+    assert (a.temb_total, a.text_total, a.text_kp, a.n_map_blocks) == (b.temb_total, b.text_total, b.text_kp, b.n_map_blocks)
+    b._plan("stream", b.prepare_cache(3)).pl.run(stream=0)             # validate-only
+    with pytest.raises(ValueError):
+        HipStreamingUNet(path, tiny_config(window_size=24, channels=(64, 128, 128, 128), cross_attention_dim=64), 16, 16, 2, device="cpu")
