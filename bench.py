@@ -201,6 +201,15 @@ def cpu_baseline(cfg, sd_cpu16, frames=2):
                        f"{sec:.2f} s/frame, {os.cpu_count()} logical cpus")
 
 
+def baseline_metric() -> str:
+    """BASELINE.json's metric string, verbatim (one streaming UNet step = one output frame)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:  # noqa: BLE001
+        return "frames/sec @512\u00d7512, 2 denoise steps; per-step latency; 1/2/4/8 GPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,7 +291,7 @@ def main():
     value = world * args.steps / elapsed
 
     result = {
-        "metric": "frames/sec @512x512, 2 denoise steps (streaming UNet step = one output frame)",
+        "metric": baseline_metric(),
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
