@@ -91,7 +91,8 @@ def per_kernel_breakdown(unet, reps=5):
 
 def tattn_variant_sweep(unet, reps=5, variants=(1, 10, 13)):
     """A/B of the streaming temporal-attention kernel variants on this frame's 40 launches (same process,
-    interleaved): ms per frame for variant 1 (register resident), 2 (chunked CH=8), 3 (chunked CH=4)."""
+    interleaved): ms per frame for variant 1 (register resident), 10 (streaming probe with the same access pattern and
+    no compute: the bandwidth bound of this geometry, NOT attention) and 13 (the LDS-DMA ring kernel, the default)."""
     import ctypes
 
     from live2diff_amd import _lib
