@@ -16,6 +16,13 @@
 //     through LDS (padded rows, conflict-free float4 writes; same-address broadcast reads).
 // Block = PB pixels x TP threads (TP = C/8), PB chosen so that the block is 256..320 threads.
 // Masked slots (bias == -inf) are never read: their softmax weight is exactly 0.
+//
+// Which kernel runs (op.i[5], 0 = auto): the SD widths with L <= 16 go to the LDS-DMA ring kernel in tattn_ring.hip
+// (variant 13, 1.00 vs 1.33 ms per cfg-2 frame); this file keeps the kernels for everything else -- register-resident
+// (1: other widths, L <= 16) and chunked (2 / 3 / 4: L = 24, 40) -- plus the builds that were used to analyse the
+// register-resident kernel on the GPU and are reachable only by asking for them: 5 (V loaded after the softmax),
+// 6 (half-size blocks), 7 (PE rows in LDS; slower), 8 / 9 (ablations: no cache loads / no score reduction; NOT
+// attention) and 10 / 11 / 12 (streaming probes with the same access pattern; NOT attention).
 #include "tattn.h"
 
 __device__ __forceinline__ float dot8(h16x8 a, h16x8 b) {
