@@ -212,3 +212,39 @@ def test_packed_weight_cache_round_trip(dry_run, tmp_path):
     b._plan("stream", b.prepare_cache(3)).pl.run(stream=0)             # validate-only
     with pytest.raises(ValueError):
         HipStreamingUNet(path, tiny_config(window_size=24, channels=(64, 128, 128, 128), cross_attention_dim=64), 16, 16, 2, device="cpu")
+
+
+def test_plan_algorithmic_work_matches_survey(dry_run):
+    """The roofline accounting of bench.py (`op_work`, per plan op) summed over the cfg-2 plan reproduces the work the
+    survey derived from the REFERENCE's layer list: 2.227 TFLOP per UNet forward, 3.04 GB of KV cache
+    streamed once, 40 temporal / 32 spatial attention launches."""
+    import importlib.util
+    import os
+
+    from live2diff_amd import _lib
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import unet_param_spec
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = sd15_config()
+    sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    unet = HipStreamingUNet(sd, cfg, 64, 64, 2, device="cpu")
+    del sd
+    kv = unet.prepare_cache(2)
+    st = unet._plan("stream", kv)
+    tot = {}
+    for j in range(len(st.pl)):
+        fl, by = bench.op_work(st.pl[j], _lib)
+        t = tot.setdefault(st.pl[j].kind, [0, 0.0, 0.0])
+        t[0] += 1; t[1] += fl; t[2] += by
+    flops = sum(t[1] for t in tot.values())
+    assert abs(flops / 2.227e12 - 1) < 5e-3, flops                     # SURVEY 8d: 2.227 TFLOP at cfg-2
+    kv_bytes = sum(c.numel() * 2 for c in kv)
+    assert abs(kv_bytes / 3.04e9 - 1) < 2e-3                           # SURVEY 8d: 3.04 GB
+    n, fl, by = tot[_lib.OP_TATTN_STREAM]
+    assert n == 40 and abs(by - (kv_bytes + 2 * kv_bytes / cfg.window_size)) < 1e-6 * by   # K+V once + (row write, q, out) = 8 N T C bytes
+    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and tot[_lib.OP_IGEMM][0] == 380
+    assert abs(tot[_lib.OP_IGEMM][1] / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
