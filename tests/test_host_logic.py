@@ -248,3 +248,58 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     assert n == 40 and abs(by - (kv_bytes + 2 * kv_bytes / cfg.window_size)) < 1e-6 * by   # K+V once + (row write, q, out) = 8 N T C bytes
     assert tot[_lib.OP_FLASH_ATTN][0] == 32 and tot[_lib.OP_IGEMM][0] == 380
     assert abs(tot[_lib.OP_IGEMM][1] / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
+
+
+def test_pipeline_mirror_keeps_the_reference_api_surface():
+    """names the Python counterpart of `StreamAnimateDiffusionDepth` must preserve (reference
+    pipeline_stream_animation_depth.py:24-666), checked on a CPU instance driven by a stand-in UNet callable -- the
+    boundary is duck-typed, exactly like the reference's TensorRT engine swap (wrapper.py:613-626)."""
+    import inspect
+    from types import SimpleNamespace
+
+    import live2diff_amd.pipeline_stream_animation_depth as M
+    S = M.StreamAnimateDiffusionDepth
+    assert M.WARMUP_FRAMES == 8 and M.WINDOW_SIZE == 16
+    for name in ("prepare_cache", "get_timesteps", "load_lora", "fuse_lora", "enable_similar_image_filter",
+                 "disable_similar_image_filter", "prepare", "warmup_engine", "update_prompt", "add_noise",
+                 "scheduler_step_batch", "initialize_attn_bias_pe_and_update_idx", "update_attn_bias", "unet_step",
+                 "encode_image", "decode_image", "encode_depth", "predict_x0_batch", "__call__", "load_warmup_unet"):
+        assert callable(getattr(S, name, None)), name
+    params = inspect.signature(S.__init__).parameters
+    for kw in ("pipe", "num_inference_steps", "t_index_list", "strength", "torch_dtype", "width", "height", "do_add_noise",
+               "use_denoising_batch", "frame_buffer_size", "clip_skip", "cfg_type"):
+        assert kw in params, kw                                        # reference __init__ kwargs (:25-39)
+
+    class FakeUNet:                                                    # the duck-typed boundary object
+        config = SimpleNamespace(in_channels=4)
+
+        def prepare_cache(self, n):
+            return [torch.zeros(n, 2, 16, 16, 64, dtype=torch.float16)]
+
+        def __call__(self, sample, timestep, **kw):
+            assert set(kw) >= {"encoder_hidden_states", "temporal_attention_mask", "depth_sample", "kv_cache", "pe_idx", "update_idx"}
+            return {"sample": sample * 0.5, "kv_cache": kw["kv_cache"]}
+
+    pipe = SimpleNamespace(device=torch.device("cpu"), vae_scale_factor=8, unet=FakeUNet(), scheduler=None)
+    s = S(pipe, num_inference_steps=50, t_index_list=[30, 40], width=32, height=32, torch_dtype=torch.float32)
+    for attr in ("batch_size", "trt_unet_batch_size", "t_list", "denoising_steps_num", "frame_bff_size", "inference_time_ema",
+                 "inference_time_list", "depth_time_ema"):
+        assert hasattr(s, attr), attr
+    assert s.batch_size == 2 and s.denoising_steps_num == 2 and s.t_list == [30, 40]
+    s.prepare_cache(32, 32, 2)
+    assert isinstance(s.kv_cache_list, list)
+    s.attn_bias, s.pe_idx, s.update_idx = s.initialize_attn_bias_pe_and_update_idx()
+    assert s.attn_bias.shape == (2, 16) and s.pe_idx.shape == (2, 16) and s.update_idx.tolist() == [8, 9]
+    # one stream-batch step through the duck-typed boundary with the reference's scheduler algebra
+    s.sub_timesteps_tensor = torch.tensor([399, 199])
+    s.prompt_embeds = torch.zeros(2, 77, 8)
+    shp = (2, 1, 1, 1, 1)
+    s.alpha_prod_t_sqrt, s.beta_prod_t_sqrt = torch.full(shp, 0.8), torch.full(shp, 0.6)
+    s.c_skip, s.c_out = torch.full(shp, 0.1), torch.full(shp, 0.9)
+    s.x_t_latent_buffer = torch.ones(1, 4, 1, 4, 4)
+    s.depth_latent_buffer = torch.zeros(1, 4, 1, 4, 4)
+    out = s.predict_x0_batch(torch.ones(1, 4, 1, 4, 4), torch.zeros(1, 4, 1, 4, 4), noise=torch.zeros(1, 4, 1, 4, 4))
+    x0 = 0.9 * (1 - 0.6 * 0.5) / 0.8 + 0.1                            # c_out (x - beta eps) / alpha + c_skip x, x = 1, eps = 0.5
+    assert out.shape == (1, 4, 1, 4, 4) and torch.allclose(out, torch.full_like(out, x0), atol=1e-6)
+    assert torch.allclose(s.x_t_latent_buffer, torch.full((1, 4, 1, 4, 4), 0.8 * x0), atol=1e-6)
+    assert s.update_idx.tolist() == [9, 8]                             # frame 1 of the reference trace (row 1 lags row 0 by a slot)
