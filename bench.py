@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--breakdown", type=int, default=1)
     ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
     ap.add_argument("--dump-plan", type=str, default="", help="write the stream plan (one row per launch) as CSV")
+    ap.add_argument("--device-step", type=int, default=0,
+                    help="time the whole pipeline step on the device (UNet + LCM step + buffer shift + re-noising + ring "
+                         "buffer as one plan, SURVEY 8f row F3) instead of the UNet boundary call; informational")
     args = ap.parse_args()
 
     from live2diff_amd import _lib, parallel
@@ -267,7 +270,26 @@ def main():
     for _ in range(2 * cfg.window_size):          # steady state: every slot unmasked
         ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
 
+    dstep = None
+    if args.device_step:
+        from live2diff_amd.scheduler import LCMSchedule
+        from live2diff_amd.stream_step_hip import HipStreamStep
+        sch = LCMSchedule()
+        sch.set_timesteps(50)
+        tl = ts.tolist()
+        al = torch.tensor([float(sch.alphas_cumprod[t]) ** 0.5 for t in tl])
+        be = torch.tensor([(1 - float(sch.alphas_cumprod[t])) ** 0.5 for t in tl])
+        sc = [sch.get_scalings_for_boundary_condition_discrete(t) for t in tl]
+        dstep = HipStreamStep(unet, kv, ts, enc, al, be, torch.tensor([float(c[0]) for c in sc]),
+                              torch.tensor([float(c[1]) for c in sc]), use_graph=bool(args.graph))
+        if N > 1:
+            dstep.load_buffers(x[1:], d[1:])
+        for _ in range(2 * cfg.window_size):      # same steady-state ring buffer, advanced on the device
+            dstep.step(x[:1], d[:1])
+
     def step():
+        if dstep is not None:
+            return {"sample": dstep.step(x[:1], d[:1])}
         bias = rb[0].to(device=dev, dtype=torch.float16, non_blocking=True)
         pe_idx, upd = rb[1].to(dev, non_blocking=True), rb[2].to(dev, non_blocking=True)
         out = unet(x, ts, encoder_hidden_states=enc, temporal_attention_mask=bias, depth_sample=d, kv_cache=kv,
@@ -301,7 +323,9 @@ def main():
                                "Live2Diff temporal attention, one independent stream per GPU",
                    "params_M": 1277.7, "kv_cache_GB_per_stream": round(kv_bytes / 1e9, 3),
                    "plan_launches": unet.plan_summary()["n_ops"], "hipgraph": bool(args.graph),
-                   "device": unet.device_name, "output_finite": finite, "default_workload": default_workload},
+                   "device": unet.device_name, "output_finite": finite, "default_workload": default_workload,
+                   "timed_region": ("pipeline step on the device: UNet + LCM step + shift + noise + ring buffer (row F3)"
+                                    if args.device_step else "UNet boundary call (+ host ring buffer and its upload)")},
     }
     if rank == 0 and args.breakdown:
         rows = per_kernel_breakdown(unet)
