@@ -312,12 +312,29 @@ def main():
     finite = bool(torch.isfinite(out["sample"]).all())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
+    # per-step latency distribution (BASELINE metric: "...; per-step latency"): a separate pass AFTER the timed region,
+    # events on the stream the plan is launched on, one per frame boundary; never allowed to fail the benchmark
+    latency = None
+    if rank == 0:
+        try:
+            n_lat = max(2, min(50, args.steps))
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_lat + 1)]
+            evs[0].record()
+            for i in range(n_lat):
+                step()
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            dts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_lat))
+            latency = {"p50_ms": round(dts[n_lat // 2], 4), "p95_ms": round(dts[min(n_lat - 1, int(0.95 * n_lat))], 4),
+                       "max_ms": round(dts[-1], 4), "frames": n_lat}
+        except Exception as e:  # noqa: BLE001
+            latency = {"error": str(e)}
 
     result = {
         "metric": baseline_metric(),
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
+        "dtype": "f16", "data": "synthetic", "latency_per_step": latency,
         "config": {"workload": f"BASELINE configs[1]: {args.height}x{args.width} image ({h}x{w} latent), {N} denoise steps, "
                                f"KV window L={cfg.window_size} (8 sink + {cfg.window_size - 8} rolling), SD-1.5 UNet widths + "
                                "Live2Diff temporal attention, one independent stream per GPU",
