@@ -31,6 +31,12 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achie
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 
 
+# (height, width, denoise steps, window L) of the BASELINE.json configurations the GPU leg can run
+WORKLOAD_NAMES = {(256, 256, 1, 12): "BASELINE configs[0]", (512, 512, 2, 16): "BASELINE configs[1]",
+                  (512, 768, 2, 24): "BASELINE configs[2]", (512, 512, 4, 16): "BASELINE configs[3] (one of the 8 streams per GPU)",
+                  (576, 1024, 2, 40): "BASELINE configs[4]"}
+
+
 def op_work(op, kinds):
     """Algorithmic work of one plan op: (flops, bytes) from the record's own fields."""
     k = op.kind
@@ -89,10 +95,10 @@ def per_kernel_breakdown(unet, reps=5):
     return rows
 
 
-def tattn_variant_sweep(unet, reps=5, variants=(1, 10, 13)):
+def tattn_variant_sweep(unet, reps=5, variants=(1, 13)):
     """A/B of the streaming temporal-attention kernel variants on this frame's 40 launches (same process,
-    interleaved): ms per frame for variant 1 (register resident), 10 (streaming probe with the same access pattern and
-    no compute: the bandwidth bound of this geometry, NOT attention) and 13 (the LDS-DMA ring kernel, the default)."""
+    interleaved): ms per frame for variant 1 (register resident) and 13 (the LDS-DMA ring kernel, the default).
+    (The analysis-only probe variants 8-12 exist in `make PROBES=1` builds only.)"""
     import ctypes
 
     from live2diff_amd import _lib
@@ -165,41 +171,49 @@ def per_op_table(unet, path, reps=10):
             f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{op_dims(op, _lib)},{us:.2f},{fl / us / 1e6 if us else 0:.2f},{by / us / 1e3 if us else 0:.1f}\n")
 
 
-def cpu_baseline(cfg, sd_cpu16, frames=2):
+def cpu_baseline(cfg, sd_cpu16, snap, frames=3, gpu_out=None):
     """The oracle (fp32 CPU restatement, `kind: port`) timed on the host cores on a bounded sample of the SAME
-    workload: `frames` timed streaming frames of cfg-2 after one untimed frame."""
+    workload, on the SAME inputs, weights, caches and ring-buffer state as the GPU leg (`snap`, taken right before
+    the GPU frame whose output is `gpu_out`): the first, untimed oracle frame therefore is an end-to-end parity
+    check of the full-size HIP frame against the oracle (`parity_rel_l2`); `frames` more frames are timed."""
     from oracle import unet_ref as O
-    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_update
     # The oracle is hundreds of small fp32 ops per frame: with one thread per logical CPU of the GPU box (256) every op
-    # pays a 256-way fork/join and a frame took 355 s (profiles/r1f); 32 threads is where it stops scaling.
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    h = w = 64
-    N = 2
+    # pays a 256-way fork/join and a frame took 355 s (round 1, profiles/r1f); 32 threads is where it stops scaling.
+    ncpu = os.cpu_count() or 1
+    threads = max(1, min(32, ncpu))
+    torch.set_num_threads(threads)
     sd32 = {k: v.float() for k, v in sd_cpu16.items()}
-    kv = O.alloc_kv_cache(cfg, h, w, N)
-    g = torch.Generator().manual_seed(0)
-    for c in kv:
-        c.normal_(generator=g)
-    rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)
-    for _ in range(2 * cfg.window_size):
-        ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
-    x = torch.randn(N, 4, 1, h, w, generator=g)
-    d = torch.randn(N, 4, 1, h, w, generator=g)
-    enc = torch.randn(N, 77, cfg.cross_attention_dim, generator=g)
-    ts = torch.tensor([399, 199])
-    times = []
+    kv = [c.float() for c in snap["kv"]]
+    rb = [t.clone() for t in snap["rb"]]
+    x, d, enc, ts = snap["x"].float(), snap["d"].float(), snap["enc"].float(), snap["ts"]
+    times, parity = [], None
     for f in range(frames + 1):
         t0 = time.perf_counter()
-        O.unet_forward(sd32, cfg, x, ts, enc, d, kv, temporal_attention_mask=rb[0], pe_idx=rb[1], update_idx=rb[2])
+        ref = O.unet_forward(sd32, cfg, x, ts, enc, d, kv, temporal_attention_mask=rb[0], pe_idx=rb[1], update_idx=rb[2])
         times.append(time.perf_counter() - t0)
+        if f == 0 and gpu_out is not None:
+            a, b = gpu_out.double().cpu().reshape(-1), ref.double().reshape(-1)
+            parity = {"rel_l2": float((a - b).norm() / b.norm()), "cosine": float(a @ b / (a.norm() * b.norm())),
+                      "max_abs": float((a - b).abs().max()), "tolerance_rel_l2": 1e-2}
         ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
-        if f >= 1 and sum(times) > 45.0:      # bounded sample: stop early on a slow host
+        if f >= 1 and sum(times) > 60.0:      # bounded sample: stop early on a slow host
             break
-    frames = max(1, len(times) - 1)
-    sec = sum(times[1:]) / frames if len(times) > 1 else times[0]
-    return dict(value=1.0 / sec, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{frames} timed frames (+1 untimed) of the same cfg-2 workload on the fp32 oracle, "
-                       f"{sec:.2f} s/frame, {os.cpu_count()} logical cpus")
+    nt = max(1, len(times) - 1)
+    sec = sum(times[1:]) / nt if len(times) > 1 else times[0]
+    more = None
+    if ncpu >= 2 * threads and sec < 20.0:    # one frame at twice the threads: shows where the port stops scaling
+        torch.set_num_threads(2 * threads)
+        t0 = time.perf_counter()
+        O.unet_forward(sd32, cfg, x, ts, enc, d, kv, temporal_attention_mask=rb[0], pe_idx=rb[1], update_idx=rb[2])
+        more = {"threads": 2 * threads, "s_per_frame": round(time.perf_counter() - t0, 3)}
+        torch.set_num_threads(threads)
+    out = dict(value=1.0 / sec, unit="frames/s", cores=threads, kind="port",
+               sample=f"{nt} timed frames (+1 untimed parity frame) of the same workload, inputs, caches and weights on the "
+                      f"fp32 oracle, {sec:.2f} s/frame at {threads} threads; {ncpu} logical cpus on the box "
+                      "(one thread per logical cpu measured 355 s/frame in round 1: fork/join bound)",
+               s_per_frame_timed=[round(t, 3) for t in times[1:]], threads_x2=more)
+    return out, parity
 
 
 def baseline_metric() -> str:
@@ -211,6 +225,27 @@ def baseline_metric() -> str:
         return "frames/sec @512\u00d7512, 2 denoise steps; per-step latency; 1/2/4/8 GPU"
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a bare shell: re-exec this command line under torch.distributed.run, one rank per
+    GPU of this node (rendezvous on 127.0.0.1, free port).  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs on this node, found {have}. Multi-GPU = one independent frame "
+              f"stream per GPU (weak scaling); run with --gpus {max(have, 1)} or on a node with {n} GPUs.", file=sys.stderr)
+        return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL over xGMI between processes needs it here
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,12 +253,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--graph", type=int, default=0, help="replay the plan from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=3)
     ap.add_argument("--tattn-variant", type=int, default=0)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--denoise-steps", type=int, default=2)
     ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--sink", type=int, default=0, help="warm-up / sink slots (default 8; 4 with --window 12 = BASELINE configs[0])")
     ap.add_argument("--breakdown", type=int, default=1)
     ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
     ap.add_argument("--dump-plan", type=str, default="", help="write the stream plan (one row per launch) as CSV")
@@ -231,6 +267,9 @@ def main():
                     help="time the whole pipeline step on the device (UNet + LCM step + buffer shift + re-noising + ring "
                          "buffer as one plan, SURVEY 8f row F3) instead of the UNet boundary call; informational")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from live2diff_amd import _lib, parallel
     from live2diff_amd.config import sd15_config
@@ -242,7 +281,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = sd15_config(window_size=args.window, sink_size=8)
+    sink = args.sink or (4 if args.window == 12 else 8)
+    cfg = sd15_config(window_size=args.window, sink_size=sink)
     N = args.denoise_steps
     h, w = args.height // 8, args.width // 8
     default_workload = (args.height, args.width, N, args.window) == (512, 512, 2, 16)
@@ -308,7 +348,9 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device=dev)
+    mine = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(mine, device=dev)
+    per_rank_fps = [round(v, 3) for v in parallel.gather_floats(args.steps / mine, device=dev)]
     finite = bool(torch.isfinite(out["sample"]).all())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
@@ -335,8 +377,10 @@ def main():
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic", "latency_per_step": latency,
-        "config": {"workload": f"BASELINE configs[1]: {args.height}x{args.width} image ({h}x{w} latent), {N} denoise steps, "
-                               f"KV window L={cfg.window_size} (8 sink + {cfg.window_size - 8} rolling), SD-1.5 UNet widths + "
+        "per_rank_frames_per_s": per_rank_fps,
+        "config": {"workload": f"{WORKLOAD_NAMES.get((args.height, args.width, N, args.window), 'custom (not a BASELINE config)')}: "
+                               f"{args.height}x{args.width} image ({h}x{w} latent), {N} denoise steps, "
+                               f"KV window L={cfg.window_size} ({sink} sink + {cfg.window_size - sink} rolling), SD-1.5 UNet widths + "
                                "Live2Diff temporal attention, one independent stream per GPU",
                    "params_M": 1277.7, "kv_cache_GB_per_stream": round(kv_bytes / 1e9, 3),
                    "plan_launches": unet.plan_summary()["n_ops"], "hipgraph": bool(args.graph),
@@ -397,7 +441,16 @@ def main():
     if rank == 0 and args.dump_plan:
         dump_plan(unet, args.dump_plan)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, frames=args.cpu_frames)
+        # same state for both legs: snapshot (inputs, caches, ring buffer) -> one GPU frame -> the oracle from the snapshot
+        snap = {"kv": [c.cpu() for c in kv], "rb": [t.clone() for t in rb], "x": x.cpu(), "d": d.cpu(), "enc": enc.cpu(),
+                "ts": ts.cpu()}
+        if dstep is None:
+            gpu_out = step()["sample"].float().cpu()
+        else:
+            gpu_out = None         # the device step owns its own ring state / noise: no like-for-like frame to compare
+        torch.cuda.synchronize()
+        result["cpu_baseline"], result["parity_vs_oracle_full_size"] = cpu_baseline(cfg, sd_cpu, snap, frames=args.cpu_frames,
+                                                                                   gpu_out=gpu_out)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

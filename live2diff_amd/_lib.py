@@ -73,9 +73,23 @@ def device_name() -> str:
     return buf.value.decode()
 
 
+_DRY_RUN = False
+
+
+def set_dry_run(on: bool):
+    """Validate-only mode (CPU test-suite): the C library checks every op's arguments and launches nothing; plans are
+    built over CPU tensors and no HIP stream is ever touched."""
+    global _DRY_RUN
+    from . import ops
+    check(lib.l2d_set_dry_run(1 if on else 0), "l2d_set_dry_run")
+    _DRY_RUN = ops.DRY_RUN = bool(on)
+
+
 def current_stream_ptr() -> int:
     """HIP stream handle of torch's current stream (the backend launches on the caller's stream, like the
     reference's PyTorch path; reference engine.py uses its own polygraphy stream + global syncs)."""
+    if _DRY_RUN:
+        return 0
     import torch
 
     return int(torch.cuda.current_stream().cuda_stream)

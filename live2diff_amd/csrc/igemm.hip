@@ -386,8 +386,12 @@ static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
     constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
     static bool attr_done = false;
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_done = true;
+        // (fails inside a stream capture: the plan's first run is always direct -- HipStreamingUNet._run; if it fails
+        // anyway the flag stays clear, the launch below reports the error and the next direct run retries)
+        if (hipFuncSetAttribute((const void *)igemm_kernel<TN, TM, MODE, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+            attr_done = true;
+        else
+            (void)hipGetLastError();
     }
     int ntn = (a.Nout + TN - 1) / TN, ntm = (a.M + TM - 1) / TM;
     dim3 grid(ntn * ntm, a.splitk, batch), block(256);

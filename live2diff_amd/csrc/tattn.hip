@@ -370,6 +370,7 @@ __global__ __launch_bounds__(TP *PB) void tattn_stream_chunked_kernel(TAttnArgs 
 // Streaming probes with the stream kernel's exact geometry (variants 10/11/12, analysis only -- the output is NOT
 // attention): MODE 0 = sum of all K and V rows, 1 = K rows only, 2 = K + V rows + the gathered PE rows.  They
 // bound what this access pattern can reach with no dependent index loads, no LDS exchange and no softmax.
+#ifdef L2D_PROBES
 template <int TP, int PB, int L, int MODE>
 __global__ __launch_bounds__(TP *PB) void tattn_probe_kernel(TAttnArgs a) {
     const int tid = threadIdx.x;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(TP *PB) void tattn_probe_kernel(TAttnArgs a) {
     }
     l2d_st8(a.out + pix * C + cc * 8, acc);
 }
+#endif
 
 template <int TP, int PB, int L>
 static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
@@ -404,6 +406,7 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
     if (v == 0) v = (L <= 16) ? 1 : 2;
     if (v == 1 && L <= 16)
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB), lds, s, a);
+#ifdef L2D_PROBES   // analysis-only builds (`make PROBES=1`): ablations / streaming probes whose output is NOT attention
     else if (v == 8 && L <= 16)
         hipLaunchKernelGGL((tattn_stream_kernel<TP, PB, (L <= 16 ? L : 16), true, 1>), dim3(nb), dim3(TP * PB), lds, s, a);
     else if (v == 9 && L <= 16)
@@ -414,6 +417,12 @@ static int launch_stream_t(const TAttnArgs &a, hipStream_t s) {
         if (v == 11) hipLaunchKernelGGL((tattn_probe_kernel<TP, PB, LL, 1>), dim3(nb), dim3(TP * PB), 0, s, a);
         if (v == 12) hipLaunchKernelGGL((tattn_probe_kernel<TP, PB, LL, 2>), dim3(nb), dim3(TP * PB), 0, s, a);
     }
+#else
+    else if (v >= 8 && v <= 12) {
+        l2d_set_error("tattn_stream: variants 8-12 are analysis probes (output is not attention); build with `make PROBES=1`");
+        return L2D_EINVAL;
+    }
+#endif
     else if (v == 7 && L <= 16)   // PE rows staged in LDS
         hipLaunchKernelGGL((tattn_stream_lds_kernel<TP, PB, (L <= 16 ? L : 16)>), dim3(nb), dim3(TP * PB),
                            lds + (size_t)2 * L * TP * 8 * sizeof(h16), s, a);

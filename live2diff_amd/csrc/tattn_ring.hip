@@ -225,9 +225,12 @@ template <int L, int HG>
 static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
     constexpr size_t LDS = (size_t)5 * 8 * 4 * 40 * 16 + (size_t)(320 * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static bool attr_done = false;
-    if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel
-        (void)hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr_done = true;
+    if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel (not inside a stream capture: the
+        // plan's first run is always direct; on failure the flag stays clear and the launch below reports the error)
+        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+            attr_done = true;
+        else
+            (void)hipGetLastError();
     }
     const int CH = a.C / 320;
     const int groups_per_unit = a.T / 8;

@@ -2,9 +2,10 @@
 
 The reference has no distributed path at all.  Streams share nothing per frame --
 weights are read-only replicas, KV-cache / latent buffers / ring indices are private -- so the only
-collectives are (a) a one-time RCCL broadcast of the fp16 weights from rank 0 (flattened into a few large
-messages: xGMI is per-link bound, big transfers amortise the ring latency), with an all-reduced checksum,
-and (b) the barrier / max / sum around the timed region of the benchmark.  Nothing on the per-frame path.
+collectives are (a) a one-time RCCL replication of the fp16 weights from rank 0, done as scatter (1/G shard per
+peer, one xGMI link each) + all-gather (all links), in a few flat 1 GB buckets, with an all-reduced checksum,
+and (b) the barrier / max / all-gather of per-rank results around the timed region of the benchmark.  Nothing on
+the per-frame path.
 
 `backend` is "nccl" (= RCCL on ROCm) on GPUs and "gloo" in the CPU tests.
 """
@@ -32,10 +33,17 @@ def init_distributed(backend: Optional[str] = None):
 
 
 def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Tensor]], device, dtype=torch.float16,
-                         src: int = 0, bucket_elems: int = 256 * 1024 * 1024) -> Dict[str, torch.Tensor]:
-    """Rank `src` holds `sd`; every rank returns a full copy on `device`.  Tensors are packed into flat buckets of
-    up to `bucket_elems` elements (512 MB fp16) -> ~5 broadcasts for the 2.56 GB UNet instead of 1 222 small ones.
-    A checksum (sum of per-bucket fp64 sums) is all-reduced (MIN == MAX) to verify the replicas."""
+                         src: int = 0, bucket_elems: int = 512 * 1024 * 1024, algo: str = "scatter_allgather") -> Dict[str, torch.Tensor]:
+    """Rank `src` holds `sd`; every rank returns a full copy on `device`.
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a root-sourced broadcast is bound by what ONE link / a
+    ring step carries.  Default algorithm, per flat bucket of up to `bucket_elems` elements (1 GB fp16: the 2.56 GB UNet
+    is 3 buckets instead of 1 222 tensors):
+        1. scatter     rank `src` sends shard g (1/G of the bucket) to peer g -- G-1 different shards leave the root over
+                       G-1 different links at once, each link carries 1/G of the bytes;
+        2. all-gather  every rank re-sends its shard to all peers (all links of all GPUs busy).
+    `algo="broadcast"` keeps the plain bucketed `dist.broadcast` for comparison.  A checksum (fp64 sum of every bucket) is
+    all-reduced with MIN and MAX, which must agree, to verify the replicas."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
@@ -49,15 +57,23 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
         while j < len(keys) and (n == 0 or n + _numel(spec[keys[j]]) <= bucket_elems):
             n += _numel(spec[keys[j]])
             j += 1
-        flat = torch.empty(n, dtype=dtype, device=device)
+        shard = (n + world - 1) // world
+        shard = (shard + 7) // 8 * 8                       # 16-byte aligned shards
+        flat = torch.empty(shard * world, dtype=dtype, device=device)
         if rank == src:
             off = 0
             for k in keys[i:j]:
                 m = _numel(spec[k])
                 flat[off:off + m].copy_(sd[k].reshape(-1).to(device=device, dtype=dtype))
                 off += m
-        dist.broadcast(flat, src=src)
-        checksum += flat.double().sum()
+            flat[n:].zero_()
+        if algo == "broadcast":
+            dist.broadcast(flat, src=src)
+        else:
+            mine = torch.empty(shard, dtype=dtype, device=device)
+            dist.scatter(mine, scatter_list=(list(flat.view(world, shard).unbind(0)) if rank == src else None), src=src)
+            _all_gather_flat(flat, mine, world, shard)
+        checksum += flat[:n].double().sum()
         off = 0
         for k in keys[i:j]:
             m = _numel(spec[k])
@@ -70,6 +86,24 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
     if not torch.equal(lo, hi):
         raise RuntimeError(f"weight broadcast checksum mismatch across ranks: {lo.item()} vs {hi.item()}")
     return out
+
+
+def _all_gather_flat(flat: torch.Tensor, mine: torch.Tensor, world: int, shard: int):
+    try:
+        dist.all_gather_into_tensor(flat, mine)
+    except (RuntimeError, NotImplementedError):            # a backend without the flat form (older gloo)
+        dist.all_gather(list(flat.view(world, shard).unbind(0)), mine)
+
+
+def gather_floats(x: float, device="cpu"):
+    """Every rank's value, in rank order (per-rank frames/s for the aggregate report); [x] without a process group."""
+    if not dist.is_initialized():
+        return [x]
+    world = dist.get_world_size()
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
 
 
 def _numel(shape) -> int:

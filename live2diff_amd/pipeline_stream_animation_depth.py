@@ -13,7 +13,9 @@ reference's public surface) but is organised around device
     keeps a second CPU-resident copy of all weights and moves it to the GPU for `prepare`, :315,338).
 
 VAE / text encoder / depth detector are the caller's objects (duck-typed exactly like the reference's
-`stream.vae`, `stream.text_encoder`, `stream.depth_detector` swap points); they are outside this path.
+`stream.vae`, `stream.text_encoder`, `stream.depth_detector` swap points); they are outside this path.  So is the
+near-duplicate frame filter (reference image_filter.py, SURVEY 2.1 #16 OUT OF SCOPE): `stream.similar_filter` is whatever
+object the caller attaches (`__call__(x) -> x | None`, `set_threshold`, `set_max_skip_frame`), e.g. the reference's own.
 """
 import time
 from typing import List, Literal, Optional, Tuple, Union
@@ -67,42 +69,14 @@ def retrieve_latents(encoder_output, generator=None):
     raise AttributeError("could not access latents of the provided encoder_output")
 
 
-class SimilarImageFilter:
-    """reference image_filter.py:7-45 (stochastic skip of near-duplicate frames)."""
-
-    def __init__(self, threshold: float = 0.98, max_skip_frame: float = 10):
-        self.threshold, self.max_skip_frame = threshold, max_skip_frame
-        self.prev_tensor, self.skip_count = None, 0
-
-    def set_threshold(self, threshold: float):
-        self.threshold = threshold
-
-    def set_max_skip_frame(self, max_skip_frame: float):
-        self.max_skip_frame = max_skip_frame
-
-    def __call__(self, x: torch.Tensor):
-        if self.prev_tensor is None:
-            self.prev_tensor = x.detach().clone()
-            return x
-        cos = F.cosine_similarity(self.prev_tensor.reshape(-1).float(), x.reshape(-1).float(), dim=0).item()
-        sample = np.random.uniform(0, 1)
-        if self.threshold >= 1:
-            skip_prob = 0
-        else:
-            skip_prob = max(0, 1 - (1 - cos) / (1 - self.threshold))
-        if skip_prob < sample:
-            self.prev_tensor = x.detach().clone()
-            return x
-        if self.skip_count > self.max_skip_frame:
-            self.skip_count = 0
-            self.prev_tensor = x.detach().clone()
-            return x
-        self.skip_count += 1
-        return None
-
-
 class _ImageProcessor:
-    """the slice of diffusers' VaeImageProcessor.preprocess the stream uses (:630): -> [B,3,H,W] in [-1,1]."""
+    """the slice of diffusers' VaeImageProcessor.preprocess the stream uses (:630): -> [B,3,H,W] in [-1,1].
+    Tensor inputs are resized with F.interpolate's default (nearest) mode like VaeImageProcessor.resize does for tensors
+    (third-party, parity unpinned).  `assume_unit_range=True` (what the reference's callers feed: frames in [0,1])
+    skips the `image.min() < 0` probe, which is a device->host sync on every frame; None keeps diffusers' probe."""
+
+    def __init__(self, assume_unit_range: Optional[bool] = None):
+        self.assume_unit_range = assume_unit_range
 
     def preprocess(self, image, height: int, width: int) -> torch.Tensor:
         if not torch.is_tensor(image):
@@ -113,8 +87,11 @@ class _ImageProcessor:
         if image.ndim == 3:
             image = image[None]
         if image.shape[-2:] != (height, width):
-            image = F.interpolate(image.float(), (height, width), mode="bilinear", align_corners=False)
-        if image.min() >= 0:
+            image = F.interpolate(image.float(), (height, width))
+        unit = self.assume_unit_range
+        if unit is None:
+            unit = bool(image.min() >= 0)
+        if unit:
             image = 2.0 * image - 1.0
         return image
 
@@ -156,7 +133,7 @@ class StreamAnimateDiffusionDepth:
         self.do_add_noise = do_add_noise
         self.use_denoising_batch = use_denoising_batch
         self.similar_image_filter = False
-        self.similar_filter = SimilarImageFilter()
+        self.similar_filter = getattr(pipe, "similar_filter", None)     # caller's object (out of scope here), duck-typed
         self.prev_image_result = None
         self.image_processor = _ImageProcessor()
         self.text_encoder = getattr(pipe, "text_encoder", None)
@@ -192,6 +169,9 @@ class StreamAnimateDiffusionDepth:
                             safe_fusing=safe_fusing)
 
     def enable_similar_image_filter(self, threshold: float = 0.98, max_skip_frame: float = 10):
+        if self.similar_filter is None:
+            raise RuntimeError("no frame filter attached: set `stream.similar_filter` (or `pipe.similar_filter`) to an object "
+                               "with __call__/set_threshold/set_max_skip_frame, e.g. the reference's SimilarImageFilter")
         self.similar_image_filter = True
         self.similar_filter.set_threshold(threshold)
         self.similar_filter.set_max_skip_frame(max_skip_frame)
@@ -236,6 +216,7 @@ class StreamAnimateDiffusionDepth:
                 prompt_embeds: Optional[torch.Tensor] = None):
         """Forward the warm-up frames ([F,3,H,W] in [0,1]) and fill the KV-cache (reference :171-344)."""
         n = self.denoising_steps_num
+        self._device_step = None          # a previous stream's device-side state (ring buffer, frame counter, rows) is stale
         if generator is None:
             self.generator = torch.Generator(device=self.device)
             self.generator.manual_seed(seed)
@@ -303,6 +284,9 @@ class StreamAnimateDiffusionDepth:
         emb = self.pipe._encode_prompt(prompt=prompt, device=self.device, num_videos_per_prompt=1,
                                        do_classifier_free_guidance=False)[0]
         self.prompt_embeds = emb.to(device=self.device, dtype=self.dtype).repeat(self.batch_size, 1, 1)
+        ds = getattr(self, "_device_step", None)
+        if ds is not None:                # the device step reads the prompt from the plan's static input buffer
+            ds.set_prompt(self.prompt_embeds)
 
     # ------------------------------------------------------------------ per-frame
     def unet_step(self, x_t_latent, depth_latent, t_list, idx: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -343,7 +327,8 @@ class StreamAnimateDiffusionDepth:
             raise ValueError("enable_device_step needs the HipStreamingUNet backend and frame_bff_size == 1")
         self._device_step = HipStreamStep(self.unet, self.kv_cache_list, self.sub_timesteps_tensor, self.prompt_embeds,
                                           self.alpha_prod_t_sqrt, self.beta_prod_t_sqrt, self.c_skip, self.c_out,
-                                          do_add_noise=self.do_add_noise, seed=seed, use_graph=use_graph)
+                                          do_add_noise=self.do_add_noise, seed=seed, use_graph=use_graph,
+                                          ring_state=self._rb)      # frames may already have run on the host path
         self._device_step.load_buffers(self.x_t_latent_buffer, self.depth_latent_buffer)
         return self._device_step
 
@@ -351,7 +336,10 @@ class StreamAnimateDiffusionDepth:
         """reference :573-623 (stream-batch shift register). `noise` lets tests inject the re-noising tensor."""
         n = self.denoising_steps_num
         ds = getattr(self, "_device_step", None)
-        if ds is not None and noise is None:
+        if ds is not None:
+            if noise is not None:
+                raise ValueError("device step is enabled: its ring buffer / latent rows live on the device and the host "
+                                 "path would run with stale state; inject noise through HipStreamStep(inject_noise=True)")
             x_0_pred_out = ds.step(x_t_latent, depth_latent)
             self.attn_bias, self.pe_idx, self.update_idx = ds.attn_bias, ds.pe_idx, ds.update_idx
             if n > 1:

@@ -4,7 +4,9 @@ The reference takes them from `diffusers.LCMScheduler` (pipeline_stream_animatio
 278-279; config configs/base_config.yaml:30-36).  diffusers is third-party and absent from the build image,
 so the documented 0.25.0 semantics are restated here (parity unpinned by the reference):
   * betas: "linear" -> linspace(beta_start, beta_end, T); "scaled_linear" -> linspace(sqrt, sqrt)^2
-  * timesteps: LCM origin steps (k * T/50 - 1, k = 1..50) reversed and strided to `num_inference_steps`
+  * timesteps: LCM origin steps (k * T/50 - 1, k = 1..50) reversed, then `num_inference_steps` of them picked at
+    indices floor(linspace(0, 50, n, endpoint=False)) (0.25.0's rule; equal to the older stride rule only when
+    50 % n == 0: n = 4 gives [999, 759, 499, 259], the stride rule would give [999, 759, 519, 279])
   * boundary-condition scalings: c_skip = s^2/((10 t)^2 + s^2), c_out = 10 t / sqrt((10 t)^2 + s^2), s = 0.5
 """
 import numpy as np
@@ -30,10 +32,11 @@ class LCMSchedule:
     def set_timesteps(self, num_inference_steps: int, device=None):
         c = self.num_train_timesteps // self.original_inference_steps
         origin = np.asarray(list(range(1, self.original_inference_steps + 1))) * c - 1
-        skipping = len(origin) // num_inference_steps
-        if skipping < 1:
+        if num_inference_steps > len(origin):
             raise ValueError("num_inference_steps must be <= original_inference_steps")
-        ts = origin[::-skipping][:num_inference_steps]
+        lcm = origin[::-1]
+        idx = np.floor(np.linspace(0, len(lcm), num=num_inference_steps, endpoint=False)).astype(np.int64)
+        ts = lcm[idx]
         self.timesteps = torch.from_numpy(ts.copy()).long()
         if device is not None:
             self.timesteps = self.timesteps.to(device)

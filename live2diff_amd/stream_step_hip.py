@@ -28,9 +28,11 @@ class HipStreamStep:
     def __init__(self, unet: HipStreamingUNet, kv_cache: List[torch.Tensor], timesteps: torch.Tensor,
                  prompt_embeds: torch.Tensor, alpha_prod_t_sqrt: torch.Tensor, beta_prod_t_sqrt: torch.Tensor,
                  c_skip: torch.Tensor, c_out: torch.Tensor, do_add_noise: bool = True, seed: int = 0,
-                 inject_noise: bool = False, use_graph: bool = False):
+                 inject_noise: bool = False, use_graph: bool = False, ring_state=None):
         """timesteps [N] int64; prompt_embeds [N,77,D]; the four scheduler tensors hold one value per row (any shape
-        with N elements), in the pipeline's dtype -- their fp16-rounded values are what the reference multiplies by."""
+        with N elements), in the pipeline's dtype -- their fp16-rounded values are what the reference multiplies by.
+        `ring_state` = (attn_bias, pe_idx, update_idx) host tensors to start from (the pipeline's current `_rb` when
+        frames already ran on the host path); None = the initial state of a fresh stream."""
         self.unet, self.kv = unet, kv_cache
         cfg, N = unet.cfg, unet.N
         self.N, self.per = N, cfg.in_channels * unet.h * unet.w
@@ -39,8 +41,8 @@ class HipStreamStep:
         unet._bind_caches(st, kv_cache)
         self.st = st
         st.in_t.copy_(timesteps.reshape(-1).expand(N))
-        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(prompt_embeds)
-        rb = ring_buffer_init(N, cfg.window_size, cfg.sink_size)
+        self.set_prompt(prompt_embeds)                # also marks the conditioning launches stale
+        rb = ring_state if ring_state is not None else ring_buffer_init(N, cfg.window_size, cfg.sink_size)
         st.in_bias.copy_(rb[0].to(torch.float16))
         st.in_pe_idx.copy_(rb[1])
         st.in_upd.copy_(rb[2])
@@ -65,6 +67,12 @@ class HipStreamStep:
         self.pl = pl
         self._graph = None
         self._warm = False
+
+    def set_prompt(self, prompt_embeds: torch.Tensor):
+        """(Re)load the static text input of the plan (reference update_prompt, pipeline :368-376)."""
+        st, cfg = self.st, self.unet.cfg
+        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(prompt_embeds)
+        self.unet.invalidate_text_cache()
 
     # ---- state the caller owns in the reference (x_t_latent_buffer / depth_latent_buffer, set by `prepare`)
     def load_buffers(self, x_t_latent_buffer: Optional[torch.Tensor], depth_latent_buffer: Optional[torch.Tensor]):
@@ -95,6 +103,7 @@ class HipStreamStep:
         c = self.unet.cfg.in_channels
         self.st.in_sample[0].copy_(x_t_latent.reshape(c, -1))
         self.st.in_depth[0].copy_(depth_latent.reshape(c, -1))
+        self.unet._ensure_cond(self.st)        # time embedding + text K / V^T: only after set_prompt / construction
         if self.use_graph and self._warm:
             if self._graph is None:             # capture on a side stream (the legacy default stream cannot be captured)
                 side = torch.cuda.Stream(device=self.unet.device)

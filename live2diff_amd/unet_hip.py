@@ -106,6 +106,7 @@ class HipStreamingUNet:
         self.use_graph = use_graph
         self.tattn_variant = tattn_variant
         self.igemm_splitk_off = False       # tuning knob: disable split-K schedules
+        self.cond_cache = os.environ.get("L2D_COND_CACHE", "1") != "0"   # 0: re-run the conditioning launches every call
         assert 1 <= text_len <= TEXT_PAD
         self.text_len = text_len           # static number of text tokens (77 for CLIP)
         self.dtype = torch.float16
@@ -311,11 +312,16 @@ class HipStreamingUNet:
         L, G = cfg.window_size, cfg.norm_num_groups
         ar = _Arena(dev)
         pl = _lib.OpList()
-        st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, arena=ar, tattn_ops=[])
+        # `cond_pl`: the launches that depend on (timestep, text) only -- time-embedding MLP + every resnet's
+        # time_emb_proj, and the K / V^T text projections of all 16 cross-attention layers (frame-invariant).
+        # They run when the conditioning changes (first frame, update_prompt, a new warm-up row), not every frame.
+        cond_pl = _lib.OpList()
+        st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, cond_pl=cond_pl, cond_key=None, arena=ar, tattn_ops=[], warm=False)
+        cur = [cond_pl]
 
         def add(opk):
             op, keep = opk
-            pl.append(op, *keep)
+            cur[0].append(op, *keep)
             return op
 
         def gemm(x1, wt, out, **kw):
@@ -544,6 +550,7 @@ class HipStreamingUNet:
                       CinP=self.text_kp, ldo=TEXT_PAD, batch=Bt, sx1=0, sw=TEXT_PAD * self.text_kp,
                       so=self.text_total * TEXT_PAD)
 
+        cur[0] = pl
         # ---- input: NCHW latents -> channels-last (padded to 8 channels), conv_in + depth mapping network
         x_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
         d_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
@@ -627,9 +634,38 @@ class HipStreamingUNet:
             st.pl._arr = None
             self._graph.pop(st.mode, None)
 
+    def invalidate_text_cache(self):
+        """Force the conditioning launches (time embedding, text K / V^T) to re-run on the next call: for callers that
+        rewrite the plan's static `in_enc` / `in_t` buffers themselves (HipStreamStep.set_prompt)."""
+        for st in self._plans.values():
+            st.cond_key = None
+
+    def _load_cond(self, st, timestep, encoder_hidden_states):
+        """Conditioning inputs -> static buffers + the `cond_pl` launches, only when they changed.  "Changed" is decided
+        on the host without a sync: the SAME tensor objects as last call (held here, so their storage cannot be recycled
+        for other data) with unchanged in-place version counters.  The reference pipeline passes `self.prompt_embeds`
+        (re-bound only by update_prompt) and one `sub_timesteps_tensor` for the whole stream; a caller that builds fresh
+        tensors every call simply gets the launches every call."""
+        cfg = self.cfg
+        key = (timestep, encoder_hidden_states, timestep._version, encoder_hidden_states._version)
+        old = st.cond_key
+        if (self.cond_cache and old is not None and len(old) == 4 and old[0] is key[0] and old[1] is key[1]
+                and old[2:] == key[2:]):
+            return
+        st.in_t.copy_(timestep.reshape(-1)[:1] if st.Bt == 1 else timestep.reshape(-1).expand(st.Bt))
+        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(encoder_hidden_states[: st.Bt])
+        st.cond_pl.run()
+        st.cond_key = key
+
+    def _ensure_cond(self, st):
+        """For callers that own the static inputs (HipStreamStep): run the conditioning launches if they are stale."""
+        if st.cond_key is None:
+            st.cond_pl.run()
+            st.cond_key = ("external",)
+
     def _run(self, st):
-        if self.use_graph:
-            g = self._graph.get(st.mode)
+        if self.use_graph and st.warm:      # the first call runs directly: the launchers' one-time kernel-attribute /
+            g = self._graph.get(st.mode)    # device queries are not allowed inside a stream capture
             if g is None:
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream())
@@ -640,6 +676,7 @@ class HipStreamingUNet:
             g.launch()
         else:
             st.pl.run()
+            st.warm = True
 
     # ------------------------------------------------------------------ the boundary call
     @torch.no_grad()
@@ -657,14 +694,13 @@ class HipStreamingUNet:
             raise ValueError(f"text length {st.text_len_rt} != static {st.text_len}")
         st.in_sample.copy_(sample.reshape(N, cfg.in_channels, -1))
         st.in_depth.copy_(depth_sample.reshape(N, cfg.in_channels, -1))
-        st.in_t.copy_(timestep.reshape(-1).expand(N))
-        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(encoder_hidden_states)
+        self._load_cond(st, timestep, encoder_hidden_states)
         st.in_bias.copy_(temporal_attention_mask)
         st.in_pe_idx.copy_(pe_idx)
         st.in_upd.copy_(update_idx)
         self._run(st)
-        out = st.out_sample.view(N, cfg.out_channels, 1, self.h, self.w)
-        if not return_dict:
+        out = st.out_sample.view(N, cfg.out_channels, 1, self.h, self.w)    # a view of the plan's static output buffer (like
+        if not return_dict:                                                  # the TensorRT engine's output binding): the next call overwrites it
             return (out, kv_cache)
         return UNetOutput(out, kv_cache)
 
@@ -681,8 +717,7 @@ class HipStreamingUNet:
         self._bind_caches(st, kv_cache, row=row)
         st.in_sample.copy_(sample[0].transpose(0, 1).reshape(F_, cfg.in_channels, -1))
         st.in_depth.copy_(depth_sample[0].transpose(0, 1).reshape(F_, cfg.in_channels, -1))
-        st.in_t.copy_(timestep.reshape(-1)[:1])
-        st.in_enc[:, : st.text_len, : cfg.cross_attention_dim].copy_(encoder_hidden_states[:1])
+        self._load_cond(st, timestep, encoder_hidden_states)
         self._run(st)
         out = st.out_sample.view(F_, cfg.out_channels, self.h, self.w).transpose(0, 1).unsqueeze(0)
         if not return_dict:
@@ -695,4 +730,4 @@ class HipStreamingUNet:
         kinds = {}
         for j in range(len(st.pl)):
             kinds[st.pl[j].kind] = kinds.get(st.pl[j].kind, 0) + 1
-        return dict(n_ops=len(st.pl), kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())
+        return dict(n_ops=len(st.pl), n_cond_ops=len(st.cond_pl), kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())

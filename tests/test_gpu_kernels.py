@@ -249,6 +249,64 @@ def test_flash_attn(L, d, Tq, Tk):
     check(out, ref, what=f"flash d{d} {Tq}x{Tk}")
 
 
+def _sdpa_ref_blocks(q, k, v, H, blk=1024):
+    """fp32 softmax(QK^T/sqrt d)V on the device in query blocks (a [H,blk,Tk] score slab at a time)."""
+    B, Tq, C = q.shape
+    d = C // H
+    out = torch.empty(B, Tq, C, dtype=torch.float32, device=q.device)
+    for b in range(B):
+        kh = k[b].float().view(-1, H, d).permute(1, 2, 0)            # [H,d,Tk]
+        vh = v[b].float().view(-1, H, d).permute(1, 0, 2)            # [H,Tk,d]
+        for q0 in range(0, Tq, blk):
+            qh = q[b, q0:q0 + blk].float().view(-1, H, d).permute(1, 0, 2)
+            p = torch.softmax(torch.matmul(qh, kh) * d ** -0.5, dim=-1)
+            out[b, q0:q0 + blk] = torch.matmul(p, vh).permute(1, 0, 2).reshape(-1, C)
+    return out
+
+
+@pytest.mark.parametrize("d,T", [(40, 6144), (40, 9216), (80, 2304), (160, 576)])
+def test_flash_attn_long_sequences(L, d, T):
+    """Self-attention lengths of BASELINE cfg-3 (64x96 latent: T = 6144 / 1536 / 384) and cfg-5 (72x128: T = 9216 / 2304 /
+    576) at the SD-1.5 head sizes, N = 2 stream rows, against fp32 attention on the same fp16 inputs."""
+    B, H = 2, 8
+    C = H * d
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q, k, v = (torch.randn(B, T, C, generator=g, device=DEV, dtype=torch.float16) for _ in range(3))
+    ref = _sdpa_ref_blocks(q, k, v, H)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
+    L.run(L.flash_attn(q, k, vt, out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C, sq=T * C, sk=T * C, svt=C * T, so=T * C))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"flash long d{d} T{T}")
+
+
+@pytest.mark.parametrize("d", [40, 80, 160])
+@pytest.mark.parametrize("scale,spike_tile", [(0.25, None), (4.0, 0), (4.0, 5), (16.0, 3)])
+def test_flash_attn_forced_rescale(L, d, scale, spike_tile):
+    """The lazy running-max rescale (only when a row's maximum grows by more than 2^8) is a rare, data-dependent branch:
+    force it.  Logits are scaled by `scale`^2 and one key (in key tile `spike_tile`) is aligned with a block of queries so
+    that their maximum jumps far past the threshold exactly there -- early tiles (0), mid-stream (5) and with huge logits
+    (16).  fp64 reference on the same fp16 inputs; every row is compared, not a sample."""
+    B, H, T = 1, 8, 640
+    C = H * d
+    q, k, v = rnd(B, T, C, seed=21) * scale, rnd(B, T, C, seed=22) * scale, rnd(B, T, C, seed=23)
+    if spike_tile is not None:
+        key = spike_tile * 64 + 17
+        k[0, key] = (q[0, 100:164].float().mean(0) * 6).half()      # strongly aligned with 64 consecutive queries
+        q[0, 300] = (k[0, key].float() * 0.5).half()                  # and one query aligned even harder
+    qh, kh, vh = (t.double().view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    ref = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh
+    ref = ref.transpose(1, 2).reshape(B, T, C)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
+    L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C,
+                       sq=T * C, sk=T * C, svt=C * T, so=T * C))
+    torch.cuda.synchronize()
+    check(out, ref, tol=4e-3, what=f"flash forced rescale d{d} x{scale} tile {spike_tile}")
+    worst = (out.double().cpu() - ref).abs().max().item()
+    assert worst <= 2e-2 * max(1.0, v.float().abs().max().item()), worst      # no O(1)-wrong row hiding inside the L2 norm
+
+
 def test_flash_attn_softmax_stress(L):
     """large logits + one dominant key per row: exercises the running-max rescale across tiles"""
     B, H, d, T = 1, 8, 40, 512
@@ -286,7 +344,12 @@ def _tattn_case(C, T, Lw, S, N, seed, ramp=True):
                                                 (64, 50, 12, 4, 1, 7), (256, 37, 16, 8, 3, 7), (320, 100, 16, 8, 2, 6),
                                                 (320, 256, 16, 8, 2, 13), (640, 64, 16, 8, 2, 13), (1280, 16, 16, 8, 2, 13),
                                                 (320, 1024, 16, 8, 3, 13), (640, 104, 12, 4, 2, 13), (1280, 8, 12, 4, 1, 13),
-                                                (320, 4096, 16, 8, 2, 13), (1280, 64, 16, 8, 2, 13), (640, 1024, 16, 8, 2, 13)])
+                                                (320, 4096, 16, 8, 2, 13), (1280, 64, 16, 8, 2, 13), (640, 1024, 16, 8, 2, 13),
+                                                # BASELINE cfg-3 (L = 24) / cfg-5 (L = 40) windows at the SD-1.5 widths: the
+                                                # chunked kernel's real shapes (T = a slice of the 64x96 / 72x128 levels)
+                                                (320, 384, 24, 8, 2, 0), (640, 96, 24, 8, 2, 0), (1280, 24, 24, 8, 2, 0),
+                                                (320, 144, 40, 8, 2, 0), (640, 36, 40, 8, 2, 0), (1280, 9, 40, 8, 2, 0),
+                                                (320, 100, 24, 8, 4, 3), (640, 50, 40, 8, 2, 3)])
 def test_tattn_stream(L, C, T, Lw, S, N, variant):
     from live2diff_amd.config import tiny_config
     from oracle import unet_ref as O

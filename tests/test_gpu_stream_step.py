@@ -242,3 +242,61 @@ def test_pipeline_frames_device_step_vs_host_path(golden, use_graph):
     for i, (a, b) in enumerate(zip(ra, rb_)):
         assert torch.equal(a, b), i
     assert all(torch.equal(a, b) for a, b in zip(ka, kb)) and torch.equal(ua, ub) and torch.equal(pa, pb)
+
+
+def test_device_step_late_enable_prompt_update_and_reprepare(golden):
+    """Round-1 advisor findings on the device step: (a) enable_device_step() AFTER frames already ran on the host path must
+    continue from the pipeline's current ring-buffer state; (b) update_prompt() must reach the device step's static text
+    input; (c) prepare() again must drop the old device step (stale ring state / frame counter); (d) once the device step
+    is on, the host path with injected noise is refused instead of running on stale state.  Each case is compared with a
+    pipeline that stays on the host path (do_add_noise=False, so both paths are deterministic)."""
+    from types import SimpleNamespace
+
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    H = W = 128
+    sd = {k: v.to(DEV) for k, v in random_state_dict(cfg, dtype=torch.float16).items()}
+    g = torch.Generator().manual_seed(6)
+    warm = [torch.rand(3, H, W, generator=g) for _ in range(cfg.sink_size)]
+    frames = [torch.rand(1, 3, H, W, generator=g) for _ in range(30)]
+    emb1, emb2 = torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g)
+
+    def make():
+        pipe = SimpleNamespace(device=torch.device(DEV), vae_scale_factor=8, unet=HipStreamingUNet(sd, cfg, H // 8, W // 8, 2),
+                               vae=_StubVAE(), depth_model=_StubDepth(), scheduler=None)
+        pipe._encode_prompt = lambda prompt, **k: ((emb2 if prompt == "two" else emb1).to(DEV),)
+        s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=[30, 40], width=W, height=H, do_add_noise=False,
+                                        warmup_frames=cfg.sink_size, window_size=cfg.window_size)
+        s.prepare_cache(H, W, 2)
+        return s
+
+    outs = []
+    for device in (False, True):
+        torch.manual_seed(0)
+        s = make()
+        s.prepare(warm, prompt_embeds=emb1, seed=3)
+        res = [s(f.to(DEV)).clone() for f in frames[:11]]            # 11 frames on the host path (rolling part mid-cycle)
+        if device:
+            s.enable_device_step()                                    # (a) late enable
+        res += [s(f.to(DEV)).clone() for f in frames[11:18]]
+        s.update_prompt("two")                                        # (b)
+        res += [s(f.to(DEV)).clone() for f in frames[18:24]]
+        if device:
+            with pytest.raises(ValueError):                           # (d)
+                s.predict_x0_batch(torch.zeros(1, 4, 1, H // 8, W // 8, device=DEV, dtype=torch.float16),
+                                   torch.zeros(1, 4, 1, H // 8, W // 8, device=DEV, dtype=torch.float16),
+                                   noise=torch.zeros(1, 4, 1, H // 8, W // 8, device=DEV, dtype=torch.float16))
+        torch.manual_seed(0)
+        s.prepare_cache(H, W, 2)
+        s.prepare(warm, prompt_embeds=emb1, seed=3)                   # (c) a new stream on the same object
+        assert getattr(s, "_device_step", None) is None
+        if device:
+            s.enable_device_step()
+        res += [s(f.to(DEV)).clone() for f in frames[24:30]]
+        outs.append(res)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), f"frame {i}: device-step pipeline diverged from the host-path pipeline"
+    assert not torch.equal(outs[0][17], outs[0][18])

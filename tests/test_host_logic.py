@@ -61,6 +61,14 @@ def test_lcm_schedule_documented_values():
     assert abs(float(c_skip) - 0.25 / (3990.0 ** 2 + 0.25)) < 1e-12
     assert abs(float(c_out) - 3990.0 / (3990.0 ** 2 + 0.25) ** 0.5) < 1e-7
     assert abs(float(s.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-7
+    # 0.25.0 picks floor(linspace(0, 50, n, endpoint=False)) of the reversed origin steps -- NOT origin[::-skip][:n];
+    # the two differ whenever 50 % n != 0 (reference configs/pixart.yaml runs 4 steps with strength 0.6 -> [499, 259])
+    assert s.set_timesteps(4).tolist() == [999, 759, 499, 259]
+    assert s.set_timesteps(6).tolist() == [999, 839, 679, 499, 339, 179]
+    assert s.set_timesteps(50).tolist() == [999 - 20 * i for i in range(50)]
+    assert s.set_timesteps(1).tolist() == [999]
+    with pytest.raises(ValueError):
+        s.set_timesteps(51)
 
 
 def test_param_count_and_layout():
@@ -108,12 +116,10 @@ def test_weight_packers_cpu():
 
 @pytest.fixture
 def dry_run():
-    from live2diff_amd import _lib, ops
-    _lib.lib.l2d_set_dry_run(1)
-    ops.DRY_RUN = True
+    from live2diff_amd import _lib
+    _lib.set_dry_run(True)
     yield
-    ops.DRY_RUN = False
-    _lib.lib.l2d_set_dry_run(0)
+    _lib.set_dry_run(False)
 
 
 @pytest.mark.parametrize("mode", ["stream", "warmup"])
@@ -236,9 +242,10 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     kv = unet.prepare_cache(2)
     st = unet._plan("stream", kv)
     tot = {}
-    for j in range(len(st.pl)):
-        fl, by = bench.op_work(st.pl[j], _lib)
-        t = tot.setdefault(st.pl[j].kind, [0, 0.0, 0.0])
+    assert len(st.cond_pl) == 6        # timestep sinusoid + 3 skinny GEMMs + text K / V^T: run when the conditioning changes
+    for op in [st.cond_pl[j] for j in range(len(st.cond_pl))] + [st.pl[j] for j in range(len(st.pl))]:
+        fl, by = bench.op_work(op, _lib)
+        t = tot.setdefault(op.kind, [0, 0.0, 0.0])
         t[0] += 1; t[1] += fl; t[2] += by
     flops = sum(t[1] for t in tot.values())
     assert abs(flops / 2.227e12 - 1) < 5e-3, flops                     # 2.227 TFLOP at cfg-2

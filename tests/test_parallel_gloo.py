@@ -20,11 +20,13 @@ WORKER = textwrap.dedent("""
     cfg = tiny_config(channels=(32, 64, 64, 64), cross_attention_dim=64)
     spec = unet_param_spec(cfg)
     sd = random_state_dict(cfg, dtype=torch.float16) if rank == 0 else None
-    out = parallel.broadcast_state_dict(spec, sd, "cpu", bucket_elems=200_000)   # forces several buckets
     ref = random_state_dict(cfg, dtype=torch.float16)
-    assert set(out) == set(ref)
-    for k in ref:
-        assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), k
+    for algo in ("scatter_allgather", "broadcast"):      # SURVEY 8e: scatter 1/G shards + all-gather (default); plain bcast
+        out = parallel.broadcast_state_dict(spec, sd, "cpu", bucket_elems=200_001, algo=algo)   # several ragged buckets
+        assert set(out) == set(ref)
+        for k in ref:
+            assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), (algo, k)
+    assert parallel.gather_floats(10.0 + rank) == [10.0, 11.0]
     # independent streams: rank r advances its ring buffer r+3 frames; states differ, nothing is shared
     rb = ring_buffer_init(2)
     for _ in range(rank + 3):
