@@ -372,6 +372,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             latency = {"error": str(e)}
 
+    # CPU-baseline / parity leg, part 1 (before the per-kernel replays below, which run each kernel family out of context
+    # and leave stale rows in the KV caches): same state for both legs = snapshot of (inputs, caches, ring buffer), then
+    # ONE more GPU frame from exactly that state; the oracle starts from the snapshot after the JSON fields are assembled.
+    snap = gpu_out = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        snap = {"kv": [c.cpu() for c in kv], "rb": [t.clone() for t in rb], "x": x.cpu(), "d": d.cpu(), "enc": enc.cpu(),
+                "ts": ts.cpu()}
+        if dstep is None:          # (the device step owns its ring state / noise: no like-for-like frame to compare)
+            gpu_out = step()["sample"].float().cpu()
+        torch.cuda.synchronize()
+
     result = {
         "metric": baseline_metric(),
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -440,15 +451,7 @@ def main():
         per_op_table(unet, args.per_op)
     if rank == 0 and args.dump_plan:
         dump_plan(unet, args.dump_plan)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # same state for both legs: snapshot (inputs, caches, ring buffer) -> one GPU frame -> the oracle from the snapshot
-        snap = {"kv": [c.cpu() for c in kv], "rb": [t.clone() for t in rb], "x": x.cpu(), "d": d.cpu(), "enc": enc.cpu(),
-                "ts": ts.cpu()}
-        if dstep is None:
-            gpu_out = step()["sample"].float().cpu()
-        else:
-            gpu_out = None         # the device step owns its own ring state / noise: no like-for-like frame to compare
-        torch.cuda.synchronize()
+    if snap is not None:
         result["cpu_baseline"], result["parity_vs_oracle_full_size"] = cpu_baseline(cfg, sd_cpu, snap, frames=args.cpu_frames,
                                                                                    gpu_out=gpu_out)
     if rank == 0:

@@ -120,20 +120,27 @@ def test_other_baseline_configs_tiny(golden, name, h, w, N, L, S, frames):
     _assert(report)
 
 
-@pytest.mark.parametrize("qk_gain,gamma_outlier", [(4.0, 1.0), (0.25, 8.0)])
-def test_tiny_unet_rollout_fp16_range(golden, qk_gain, gamma_outlier):
-    """Weights away from unit gain: every attention's q / k projection scaled by `qk_gain` (logits x qk_gain^2: peaky
-    softmax -> the flash kernel's lazy running-max rescale and the temporal softmax see large score ranges; x 1/16: flat)
-    and one outlier channel per normalisation layer (gamma x `gamma_outlier`: activations far from N(0,1), as in real
-    SD-1.5).  Tolerance: the q / k the kernels read are fp16-rounded where the fp32 oracle keeps full precision, and a
-    logit of magnitude m carries an absolute error ~ m * 2^-11 into the exponent, so the stated bound here is
-    rel-L2 <= 3e-2 / cosine >= 0.999 (unit-gain rollouts: 1e-2 / 0.9995)."""
+_LATE = ("up_blocks.3.attentions.2", "up_blocks.3.motion_modules.2")
+
+
+@pytest.mark.parametrize("qk_gain,where,gamma_outlier", [(4.0, _LATE, 1.0), (0.25, None, 8.0)])
+def test_tiny_unet_rollout_fp16_range(golden, qk_gain, where, gamma_outlier):
+    """Weights away from unit gain, at the level of the whole UNet (the kernels' own extreme-logit cases are
+    test_gpu_kernels.py::test_flash_attn_forced_rescale):
+      * q / k projections x 4 (logits x 16: near one-hot softmax, the flash kernel's lazy rescale fires on most tiles) in
+        the LAST spatial transformer and the LAST motion module.  Only there on purpose: with x 4 in every attention the
+        network itself is ill-conditioned -- the fp32 oracle run twice, once with its activations rounded to fp16 at the
+        points where the kernels round, diverges by rel-L2 0.75 (x 2: 0.35), so no fp16 implementation, the reference's
+        included, can be compared with an fp32 run; restricted to the two late modules that self-divergence is 7.5e-3;
+      * q / k x 0.25 everywhere (flat softmax) plus one outlier channel per normalisation layer (gamma x 8: activations far
+        from N(0,1), as in real SD-1.5); oracle self-divergence 2.4e-3.
+    Stated bound: rel-L2 <= 3e-2, cosine >= 0.999 (unit-gain rollouts: 1e-2 / 0.9995); caches <= 5e-3."""
     from live2diff_amd.config import tiny_config
     cfg = tiny_config(channels=(64, 128, 256, 256), cross_attention_dim=64)
 
     def mutate(sd):
         for k in sd:
-            if k.endswith(("to_q.weight", "to_k.weight")):
+            if k.endswith(("to_q.weight", "to_k.weight")) and (where is None or k.startswith(where)):
                 sd[k] = (sd[k].float() * qk_gain).half()
             elif (".norm" in k or "norms." in k or "ff_norm" in k) and k.endswith(".weight"):
                 sd[k][3] = (sd[k][3].float() * gamma_outlier).half()
