@@ -56,7 +56,8 @@ enum {
  *   p7 16-byte zero page (padding source)   p8 split-K workspace [batch][S][M][round_up(Nout,4)] float
  *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch) i22 tile (0 auto, 1 = 128x128,
  *   2 = 64x64; + 16 = weight-tile-major block order: each XCD's L2 holds a band of output channels, for
- *   weight-dominated shapes) i23 pipeline variant (igemm.hip launch_p)
+ *   weight-dominated shapes; + 32 = direct register -> global epilogue (8-byte pieces) instead of the default one that
+ *   transposes the tile through LDS and stores whole rows with 16 bytes per lane) i23 pipeline variant (igemm.hip launch_p)
  *
  * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
  *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)

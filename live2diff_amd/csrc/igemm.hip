@@ -49,7 +49,7 @@ struct IGemmArgs {
     const h16 *zero;   // >= 16 bytes of zeros
     float *ws;         // split-K workspace [S][M][NoutP] fp32
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
-    int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order;
+    int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order, epl;
     long long sx1, sw, so, sres;
 };
 
@@ -89,7 +89,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
 
 // MODE 0: linear / 1x1 (taps = 1);  MODE 1: 3x3, single input, no upsample (fast gather);  MODE 2: 3x3 generic
 template <int TN, int TM, int MODE, int BK, int NS>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
+__global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_kernel(IGemmArgs a) {
     constexpr int NI = TN / 32;        // 16-row fragments per wave along channels
     constexpr int MI = TM / 32;        // 16-col fragments per wave along tokens
     constexpr int SPR = BK / 8;        // 16-byte slots per LDS row (4 or 8)
@@ -143,6 +143,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
     const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
     const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
 
+    // issue_w() / issue_x() are called for consecutive stages kb, kb+1, ...: ring slot, k offset and the conv tap are
+    // tracked incrementally (no division / modulo in the loop); everything except the final add/select is wave-uniform
+    int is_slot = 0, is_tap = 0, is_cb = kb * BK;
+    if (MODE != 0) {
+        is_tap = (kb * BK) / a.CinP;
+        is_cb = kb * BK - is_tap * a.CinP;
+    }
+
     // ---- per-lane DMA descriptors.  Within an RPI-row group lane l serves row l/SPR, physical slot l%SPR.
     const int lrow = lane / SPR, pslot = lane % SPR;
     const h16 *wptr[NIW];      // advances by wadv (BK or 0) halfs per stage
@@ -156,6 +164,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         wptr[j] = ok ? wp + (long long)n * a.Kp + ls * 8 + (long long)kb * BK : a.zero;
         wadv[j] = ok ? BK : 0;
     }
+    auto issue_w = [&]() {
+        h16 *st = smem + is_slot * STAGE;
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const int grp = j * 4 + wave;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(wptr[j]), L2D_LPTR(st + grp * RPI * BK), 16, 0, 0);
+            wptr[j] += wadv[j];
+        }
+    };
+    // The weight tile of the first stage needs nothing but the kernel arguments and the block id: its DMA leaves before
+    // the token-row descriptors (integer divisions, 9-tap masks) are computed, so that arithmetic runs under the first
+    // (cold: the previous kernel's end flushed the L2s) memory round trip instead of in front of it.
+    if (kb < ke) issue_w();
+
     // token rows: xoff = element offset of (row, channel slot) from x1 for tap (0,0) [MODE 1] / for k = 0 [MODE 0]
     long long xoff[NIX];
     int xls[NIX], xmask[NIX];          // xmask: bit t = tap t in bounds (MODE 1); bit 0 = row valid (MODE 0)
@@ -188,21 +210,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         }
     }
 
-    // issue() is called for consecutive stages kb, kb+1, ...: ring slot, k offset and the conv tap are tracked
-    // incrementally (no division / modulo in the loop); everything except the final add/select is wave-uniform
-    int is_slot = 0, is_tap = 0, is_cb = kb * BK;
-    if (MODE != 0) {
-        is_tap = (kb * BK) / a.CinP;
-        is_cb = kb * BK - is_tap * a.CinP;
-    }
-    auto issue = [&]() {
+    auto issue_x = [&]() {
         h16 *st = smem + is_slot * STAGE;
-#pragma unroll
-        for (int j = 0; j < NIW; ++j) {
-            const int grp = j * 4 + wave;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(wptr[j]), L2D_LPTR(st + grp * RPI * BK), 16, 0, 0);
-            wptr[j] += wadv[j];
-        }
         if (MODE == 0) {
             const bool two = a.C2 > 0;
 #pragma unroll
@@ -248,6 +257,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         is_cb += BK;
         if (MODE != 0 && is_cb >= a.CinP) { is_cb -= a.CinP; ++is_tap; }
     };
+    auto issue = [&]() { issue_w(); issue_x(); };
+
+    // ---- epilogue operands that do not depend on the accumulators are fetched NOW (plain loads, older than every token
+    // DMA in the in-order VMEM queue: the loop's counted waits cover them), not after the K loop where each would be one
+    // more dependent (cold) round trip on the block's critical path.
+    const int NoutO = (a.epi == 1) ? (a.Nout >> 1) : a.Nout;            // GEGLU halves the output width
+    const bool vec = a.epl && gridDim.y == 1 && ((a.ldo | NoutO) & 7) == 0 && (((unsigned long long)outp) & 15) == 0 &&
+                     (!resp || ((a.ldr & 7) == 0 && (((unsigned long long)resp) & 15) == 0));
+    constexpr bool RES_EARLY = (TN * TM <= 64 * 64);   // 8 + 8 VGPRs; the 128x128 tile would need 32 + 16 across the loop and
+                                                       // drop from 3 to 2 blocks per CU: it loads them when the loop ends
+    constexpr int CPRN = TN / 8;                                        // 16-byte chunks per output row (non-GEGLU)
+    constexpr int EPI_IT = (TM * CPRN) / 256;
+    f32x4 biasv[NI];
+    h16x8 resv[RES_EARLY ? EPI_IT : 1];
+    bool rb_in_bias = false;
+    auto load_bias = [&]() {
+        const float *rbp = nullptr;
+        if (a.rowbias) {
+            const int mlast = (m0 + TM <= a.M ? m0 + TM : a.M) - 1;
+            if (m0 / a.rows_per_bias == mlast / a.rows_per_bias) {      // the whole tile lies in one sample
+                rbp = a.rowbias + (long long)(m0 / a.rows_per_bias) * a.ldrb;
+                rb_in_bias = true;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0 + wn * (TN / 2) + i * 16 + lg * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.Nout) {
+                if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + n);
+                if (rbp) b += *reinterpret_cast<const f32x4 *>(rbp + n);
+            }
+            biasv[i] = b;
+        }
+    };
+    if (vec && RES_EARLY) {
+        load_bias();
+        if (resp) {
+#pragma unroll
+            for (int it = 0; it < EPI_IT; ++it) {
+                const int c = it * 256 + tid, row = c / CPRN, cc = c % CPRN;
+                const int m = m0 + row, n = n0 + cc * 8;
+                resv[it] = (m < a.M && n < a.Nout) ? l2d_ld8(resp + (long long)m * a.ldr + n) : l2d_zero8();
+            }
+        }
+    }
+    if (kb < ke) issue_x();
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -289,9 +345,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
         cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
     };
 
-    // prologue: NS-1 stages in flight
+    // prologue: NS-1 stages in flight (stage kb went out above)
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
+    for (int s = 1; s < NS - 1; ++s)
         if (kb + s < ke) issue();
     // steady state: stage kt has landed when at most (NS-2) younger stages are still outstanding
     int kt = kb;
@@ -323,6 +379,82 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmArgs a) {
                 if (n >= a.Nout) continue;
                 *reinterpret_cast<f32x4 *>(wsp + (long long)m * NoutP + n) = acc[i][j];
             }
+        }
+        return;
+    }
+    if (vec) {
+        // ---- epilogue through LDS: the accumulator layout gives a lane 4 channels of one token (8-byte pieces, 16 rows
+        // of 32 bytes per store instruction); the finished fp16 tile is therefore transposed through the (now idle) ring
+        // into [token][channel] rows and written back as whole rows with 16 bytes per lane, residual added on the way
+        // with 16-byte loads.  Rounding points are those of the reference's fp16 graph: conv / linear output (bias,
+        // activation in fp32) -> fp16, then the residual add in fp16.
+        const int pitch = (a.epi == 1 ? TN / 2 : TN) + 8;               // halfs; row stride = 16 B mod 32 B
+        h16 *ot = smem;
+        if (!RES_EARLY) load_bias();
+        __syncthreads();                                                // every wave is done reading the last stage
+        if (a.epi == 1) {
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int row = wm * (TM / 2) + j * 16 + li;
+#pragma unroll
+                for (int p = 0; p < NI / 2; ++p) {
+                    const int col = wn * (TN / 4) + p * 16 + lg * 4;
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[2 * p][j][r] + biasv[2 * p][r];
+                        const float g = acc[2 * p + 1][j][r] + biasv[2 * p + 1][r];
+                        o[r] = (h16)(v * l2d_gelu(g));
+                    }
+                    *reinterpret_cast<h16x4 *>(ot + row * pitch + col) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int row = wm * (TM / 2) + j * 16 + li;
+                const float *rb = (a.rowbias && !rb_in_bias)
+                                      ? a.rowbias + (long long)((m0 + row < a.M ? m0 + row : a.M - 1) / a.rows_per_bias) * a.ldrb
+                                      : nullptr;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int col = wn * (TN / 2) + i * 16 + lg * 4;
+                    f32x4 v = acc[i][j] + biasv[i];
+                    if (rb && n0 + col < a.Nout) v += *reinterpret_cast<const f32x4 *>(rb + n0 + col);
+                    if (a.epi == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = l2d_silu(v[r]);
+                    }
+                    h16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+                    *reinterpret_cast<h16x4 *>(ot + row * pitch + col) = o;
+                }
+            }
+        }
+        constexpr int CPRN_LOG = (CPRN == 16) ? 4 : 3;
+        const int cshift = (a.epi == 1) ? CPRN_LOG - 1 : CPRN_LOG;      // 16-byte chunks per output row = 1 << cshift
+        const int n0o = (a.epi == 1) ? (n0 >> 1) : n0;
+        h16x8 rlate[RES_EARLY ? 1 : EPI_IT];
+        if (!RES_EARLY && resp) {                                       // big tile: residual loads fly during the transpose
+#pragma unroll
+            for (int it = 0; it < EPI_IT; ++it) {
+                const int c = it * 256 + tid, row = c / CPRN, cc = c % CPRN;
+                const int m = m0 + row, n = n0 + cc * 8;
+                rlate[it] = (m < a.M && n < a.Nout) ? l2d_ld8(resp + (long long)m * a.ldr + n) : l2d_zero8();
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EPI_IT; ++it) {
+            const int c = it * 256 + tid;
+            const int row = c >> cshift, cc = c & ((1 << cshift) - 1);
+            if (row >= TM) break;                                       // GEGLU tiles have half the chunks
+            const int m = m0 + row, n = n0o + cc * 8;
+            if (m >= a.M || n >= NoutO) continue;
+            h16x8 v = l2d_ld8(ot + row * pitch + cc * 8);
+            if (resp) v = v + (RES_EARLY ? resv[RES_EARLY ? it : 0] : rlate[RES_EARLY ? 0 : it]);
+            l2d_st8(outp + (long long)m * a.ldo + n, v);
         }
         return;
     }
@@ -410,9 +542,9 @@ static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
         case 4: launch_v<TN, TM, MODE, 32, 3>(a, batch, s); return L2D_OK;
         case 5: launch_v<TN, TM, MODE, 64, 2>(a, batch, s); return L2D_OK;
         case 6: launch_v<TN, TM, MODE, 128, 2>(a, batch, s); return L2D_OK;
-        case 7: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 128, 3>(a, batch, s); return L2D_OK;
-        case 8: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 6>(a, batch, s); return L2D_OK;
-        case 9: if (TN + TM > 128) break; launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK;
+        case 7: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 128, 3>(a, batch, s); return L2D_OK; } break;
+        case 8: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 64, 6>(a, batch, s); return L2D_OK; } break;
+        case 9: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK; } break;
     }
     return L2D_EINVAL;
 }
@@ -437,6 +569,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.splitk = op->i[21] > 0 ? op->i[21] : 1;
     int tile = op->i[22] & 15; // 0 auto, 1 = 128x128, 2 = 64x64
     a.order = (op->i[22] >> 4) & 1;   // XCD tile order: 0 token-tile major, 1 weight-tile major
+    a.epl = ((op->i[22] >> 5) & 1) ? 0 : 1;   // + 32: direct (register -> global, 8-byte pieces) epilogue instead of the LDS-staged one
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.Kp = a.taps * a.CinP;
@@ -444,7 +577,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         a.M <= 0 || a.Nout <= 0 || (a.C1 % 8) || (a.C2 % 8) || (a.C2 > 0 && !a.x2) || a.C1 + a.C2 > a.CinP ||
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
-        (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1)) || (a.stride != 1 && a.stride != 2) ||
+        (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
         (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 9 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",

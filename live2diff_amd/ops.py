@@ -153,8 +153,9 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
         assert rowbias.dtype == torch.float32
     if splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
+    direct_epi = 32 if os.environ.get("L2D_IGEMM_EPI", "1") == "0" else 0     # A/B knob: register -> global epilogue
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
-            rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order), variant]
+            rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order) + direct_epi, variant]
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
