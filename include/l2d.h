@@ -70,6 +70,9 @@ enum {
  *                reference call sites attention.py:243,250-255)
  *   p0 q [B][Tq][ldq] p1 k [B][Tk][ldk] p2 vt [B][H*d][ldvt] (V transposed) p3 out [B][Tq][ldo]
  *   i0 B i1 H i2 d i3 Tq i4 Tk i5 ldq i6 ldk i7 ldvt i8 ldo ; l0 q batch stride l1 k l2 vt l3 out
+ *   p4 16-byte zero page (DMA source of keys beyond Tk; 0 selects the register-staged kernel)
+ *   i9 variant: 0 auto (LDS-DMA ring kernel, flash_attn_ring.hip), 1 register-staged kernel, 2 / 3 ring kernel with
+ *   32 / 16 query rows per wave.  V^T columns in [Tk, ldvt) may hold anything.
  *
  * L2D_OP_TATTN_STREAM  fused streaming temporal attention with multi-timestep KV-cache
  *                (reference stream_motion_module.py:99-213)

@@ -249,6 +249,8 @@ static void launch_fa(const FAArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, s, a);
 }
 
+int l2d_launch_flash_ring(const l2d_op *op, int qs, hipStream_t s);   // flash_attn_ring.hip
+
 int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
     FAArgs a;
     a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
@@ -261,7 +263,27 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
                       a.Tq, a.Tk, a.ldvt);
         return L2D_EINVAL;
     }
+    const int variant = op->i[9];   // 0 auto (LDS-DMA ring kernel when its alignment rules hold), 1 register-staged kernel,
+                                    // 2 / 3 ring kernel with 32 / 16 query rows per wave
+    if (variant < 0 || variant > 3) {
+        l2d_set_error("flash_attn(tag %d): unknown variant %d", op->tag, variant);
+        return L2D_EINVAL;
+    }
+    const bool ring_ok = op->p[4] && (a.d % 8) == 0 && ((((uintptr_t)a.k) | ((uintptr_t)a.vt)) & 15) == 0 &&
+                         ((a.sk | a.svt) % 8) == 0;
+    if (variant >= 2 && !ring_ok) {
+        l2d_set_error("flash_attn(tag %d): ring variant needs p4 = zero page, d %% 8 == 0 and 16-byte aligned K / V^T", op->tag);
+        return L2D_EINVAL;
+    }
     L2D_DRY_RETURN();
+    if (variant != 1 && ring_ok) {
+        int rc = l2d_launch_flash_ring(op, variant == 2 ? 2 : (variant == 3 ? 1 : 0), s);
+        if (rc != L2D_OK) {
+            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,80,160)", op->tag, a.d);
+            return rc;
+        }
+        return l2d_check_launch("flash_attn_ring", op->tag);
+    }
     switch (a.d) {
         case 8: launch_fa<8>(a, s); break;
         case 16: launch_fa<16>(a, s); break;

@@ -1,0 +1,370 @@
+// Flash attention on MFMA for gfx950, LDS-DMA ring version: spatial self-attention (T x T, T up to 9216) and text
+// cross-attention (T x 77) of the SD-1.5 transformer blocks -- the SDPA call inside diffusers' `Attention` that the
+// reference reaches from attention.py:243 (attn1) and :250-255 (attn2).
+//
+//   O[q][:] = softmax_k( Q[q].K[k] / sqrt(d) ) . V[k][:]        per (batch b, head h), no mask
+//
+// Same "swapped" formulation as flash_attn.hip (S^T = K.Q^T, O^T += V^T.P^T with v_mfma_f32_16x16x32_f16: the S^T
+// accumulator layout IS a legal k-slot assignment of the second MFMA's B operand, so P never leaves registers).  What
+// changed against that first kernel, which the round-1 PMC pass showed at 21.7 % MFMA-busy with 27 % of its LDS cycles
+// lost to bank conflicts and every K / V^T byte staged through VGPRs one tile ahead:
+//   * K and V^T tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4` (16 B per lane, no VGPR round trip) into an NS-stage
+//     ring; one raw `s_barrier` per key tile and a counted `s_waitcnt vmcnt((NS-2) * LPS)`: NS-1 tiles are always in
+//     flight.  The old kernel prefetched ONE tile through registers: with one block per CU (T = 1024 / 256 levels) a tile
+//     took as long as a memory round trip (~1.8 us for ~0.3 us of MFMA work).
+//   * The LDS image of a DMA is lane-linear (wave-uniform base + 16 * lane), so rows cannot be padded; the bank swizzle is
+//     applied on the SOURCE side instead (a lane fetches the logical 16-byte slot  p ^ swz(row)  of its row) and again on the
+//     fragment reads.  K is kept as KK sub-tiles of [64 keys][32 halfs] (64-byte rows, slot ^ ((row>>1)&3): the igemm BK = 32
+//     image, conflict-free for the ds_read_b128 lane groups); V^T as [d rows][64 keys] (128-byte rows, slot ^ ((row>>1)&7):
+//     conflict-free for the two 8-byte reads per fragment).  Zero padding (d = 40 -> 64 in QK^T, -> 48 rows in PV) and the
+//     row of ones that yields the softmax denominator on the matrix cores are written ONCE per ring slot; the DMA never
+//     touches them (exec-masked lanes), so padding costs no memory traffic.
+//   * Softmax: Q is pre-scaled by log2(e)/sqrt(d) when it is loaded (fp16, one more rounding of the size Q already
+//     carries) and the running reference -m is the accumulator INPUT of the first QK^T MFMA, so the MFMA result is already
+//     s*c - m: a probability is ONE v_exp_f32 (the old kernel: FMA + exp).  The reference is only raised -- and O, l rescaled,
+//     in a wave-uniform branch, with the pending tile's scores adjusted before they are exponentiated -- when some row
+//     exceeds it by more than 2^8 (p <= 256 is harmless in fp16; O, l are fp32).
+//   * Query rows per wave are a template parameter (32 or 16): levels with few queries (T <= 1024) get twice the blocks.
+#include <type_traits>
+
+#include "common.h"
+
+#define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
+#define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+struct FARArgs {
+    const h16 *q, *k, *vt, *zero;
+    h16 *out;
+    int B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo;
+    long long sq, sk, svt, so;
+};
+
+// max over the 4 lanes {li, li+16, li+32, li+48} that share a query row, without the LDS round trips of ds_bpermute:
+// v_permlane16_swap / v_permlane32_swap exchange half-rows / half-waves between two registers
+__device__ __forceinline__ float far_row_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int D>
+struct FARCfg {
+    static constexpr int KK = (D + 31) / 32;              // [64][32] K sub-tiles (QK^T contraction steps)
+    static constexpr int D16 = (D + 15) / 16;             // 16-row blocks of O^T
+    static constexpr int DV = D16 * 16;                   // V^T rows in LDS
+    static constexpr bool ONES = (D % 16) != 0;           // a spare padded row of V^T carries ones -> softmax denominator
+    static constexpr int KBYTES = KK * 64 * 32 * 2;
+    static constexpr int VBYTES = DV * 64 * 2;
+    static constexpr int STAGE = KBYTES + VBYTES;         // bytes
+    static constexpr int NS = (STAGE * 4 <= 60 * 1024) ? 4 : 3;
+    static constexpr int NVI = (D + 7) / 8;               // V^T DMA wave-instructions per tile (8 rows each)
+    static constexpr int VPW = (NVI + 3) / 4;             // ... per wave (waves without a real one issue a dummy)
+    static constexpr int LPS = KK + VPW;                  // DMA instructions per wave per stage
+    static constexpr int LDS = NS * STAGE + 1024;         // + 1 KB landing zone for the dummy DMAs
+};
+
+template <int D, int QS>
+__device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
+    using Cf = FARCfg<D>;
+    constexpr int KK = Cf::KK, D16 = Cf::D16, DV = Cf::DV, NS = Cf::NS, LPS = Cf::LPS, VPW = Cf::VPW, NVI = Cf::NVI;
+    constexpr int STAGE_H = Cf::STAGE / 2, KH = Cf::KBYTES / 2;      // halfs
+    extern __shared__ __attribute__((aligned(16))) h16 smem[];      // the ONLY LDS object: ring, then the dummy zone
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
+    const h16 *qp = a.q + (long long)b * a.sq + h * D;
+    const h16 *kp = a.k + (long long)b * a.sk + h * D;
+    const h16 *vp = a.vt + (long long)b * a.svt + (long long)h * D * a.ldvt;
+    h16 *op = a.out + (long long)b * a.so + h * D;
+    const int nt = (a.Tk + 63) / 64;
+
+    // ---- static LDS content, written once: zeros everywhere (QK^T / PV padding), ones in V^T row D of every stage
+    {
+        const h16x8 z = l2d_zero8();
+        for (int i = tid; i < (Cf::LDS / 16); i += 256) l2d_st8(smem + i * 8, z);
+        if (Cf::ONES) {
+            __syncthreads();
+            h16x8 one;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) one[e] = (h16)1.0f;
+            if (tid < NS * 8) l2d_st8(smem + (tid >> 3) * STAGE_H + KH + D * 64 + (tid & 7) * 8, one);   // a full row: swizzle-invariant
+        }
+    }
+
+    // ---- Q fragments (B operand), pre-scaled by log2(e) / sqrt(d): lane (j = li, g = lg) holds Q[q0 + qs*16 + j][kk*32 + 8g ..]
+    const float c2e = rsqrtf((float)D) * 1.4426950408889634f;
+    h16x8 qf[QS][KK];
+    {
+        h16x8 sc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc[e] = (h16)c2e;
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int qr = q0 + qs * 16 + li, dc = kk * 32 + lg * 8;
+                qf[qs][kk] = (qr < a.Tq && dc < D) ? l2d_ld8(qp + (long long)qr * a.ldq + dc) * sc : l2d_zero8();
+            }
+    }
+
+    // ---- DMA descriptors (tile-invariant parts).  K sub-tile kk: this wave fills rows 16w .. 16w+15, lane l = (row l>>2, physical slot l&3).
+    const int krow = wave * 16 + (lane >> 2);
+    const int kcol = (((lane & 3) ^ ((krow >> 1) & 3)) << 3);             // logical column (halfs) inside the sub-tile
+    // V^T: wave-instruction j fills rows 8j .. 8j+7, lane l = (row l>>3, physical slot l&7); this wave owns j = wave, wave+4, ...
+    int vrow[VPW], vkey[VPW];
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int j = wave + 4 * i;
+        vrow[i] = j * 8 + (lane >> 3);
+        vkey[i] = (((lane & 7) ^ ((vrow[i] >> 1) & 7)) << 3);             // first key (within the tile) of the logical slot
+    }
+    h16 *dummy = smem + NS * STAGE_H;
+
+    int is_slot = 0, is_key0 = 0;
+    auto issue = [&]() {                                                  // LPS DMA wave-instructions, always
+        h16 *st = smem + is_slot * STAGE_H;
+        const int key = is_key0 + krow;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int col = kk * 32 + kcol;
+            if (col < D) {                                                // padding columns stay zero: lane masked off
+                const h16 *src = (key < a.Tk) ? kp + (long long)key * a.ldk + col : a.zero;
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + kk * 2048 + wave * 512), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPW; ++i) {
+            const int j = wave + 4 * i;                                   // wave-uniform
+            if (j < NVI) {
+                if (vrow[i] < D) {
+                    const int key = is_key0 + vkey[i];
+                    const h16 *src = (key < a.Tk) ? vp + (long long)vrow[i] * a.ldvt + key : a.zero;
+                    __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + KH + j * 512), 16, 0, 0);
+                }
+            } else {
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(a.zero), L2D_LPTR(dummy), 16, 0, 0);   // keeps vmcnt bookkeeping uniform
+            }
+        }
+        is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
+        is_key0 += 64;
+    };
+
+    // fragment read offsets (halfs, relative to the stage base); the swizzle terms are tile- and block-row-invariant
+    const int kswz = (li >> 1) & 3, vswz = (li >> 1) & 7;
+    const int koff = li * 32 + ((lg ^ kswz) << 3);                        // + kk*2048 + ks*512
+    int voff[2][2];                                                       // [c2][half]: + ds*1024
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            voff[c2][hh] = KH + li * 64 + (((c2 * 4 + (lg >> 1) + 2 * hh) ^ vswz) << 3) + (lg & 1) * 4;
+
+    f32x4 oacc[D16][QS];
+#pragma unroll
+    for (int ds = 0; ds < D16; ++ds)
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) oacc[ds][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mref[QS], lrow[QS];
+    f32x4 cinit[QS];                                                      // -mref, the accumulator input of the first QK^T MFMA
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { mref[qs] = 0.f; lrow[qs] = 0.f; cinit[qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    int cp_slot = 0;
+    // FIRST: tile 0 fixes the reference (no previous one); LAST: the only tile that can hold keys >= Tk.  Both are
+    // compile-time so the steady-state body carries neither the masking selects nor the first-tile test.
+    auto compute = [&](int kt, auto first_tag, auto last_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        const h16 *st = smem + cp_slot * STAGE_H;
+        f32x4 sacc[4][QS];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs)
+                    sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][kk], kk == 0 ? cinit[qs] : sacc[ks][qs], 0, 0, 0);
+            }
+        if (LAST && (kt + 1) * 64 > a.Tk) {                               // keys beyond Tk exist in the last tile only
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((kt * 64 + ks * 16 + lg * 4 + r) >= a.Tk) sacc[ks][qs][r] = -3.0e38f;
+        }
+        h16x8 pf[2][QS];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            float mx = fmaxf(fmaxf(sacc[0][qs][0], sacc[0][qs][1]), fmaxf(sacc[0][qs][2], sacc[0][qs][3]));
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks)
+                mx = fmaxf(fmaxf(mx, fmaxf(sacc[ks][qs][0], sacc[ks][qs][1])), fmaxf(sacc[ks][qs][2], sacc[ks][qs][3]));
+            mx = far_row_max(mx);
+            // sacc already is  s*c - mref.  Raise the reference (rarely after the first tile): everything still at the old
+            // reference -- O, l and THIS tile's not yet exponentiated scores -- is moved to the new one exactly once.
+            if (FIRST || __any(mx > 8.0f)) {
+                const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);      // (first tile: O = l = 0, any finite alpha will do)
+                mref[qs] += delta;
+                lrow[qs] *= alpha;
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) sacc[ks][qs] -= delta;
+                cinit[qs] = (f32x4){-mref[qs], -mref[qs], -mref[qs], -mref[qs]};
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[ks][qs][r]);
+                    if (!Cf::ONES) psum += pv;
+                    pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
+                }
+            if (!Cf::ONES) lrow[qs] += psum;
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int ds = 0; ds < D16; ++ds) {
+                const h16x4 lo = *reinterpret_cast<const h16x4 *>(st + ds * 1024 + voff[c2][0]);
+                const h16x4 hi = *reinterpret_cast<const h16x4 *>(st + ds * 1024 + voff[c2][1]);
+                const h16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs)
+                    oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+            }
+        cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
+    };
+
+    // V^T columns in [Tk, round_up(Tk, 8)) of the last tile may hold anything (the producer pads rows to 16 bytes): P is
+    // exactly 0 there, but 0 * NaN is not.  They are cleared in LDS after the tile has landed.
+    auto scrub_last = [&]() {
+        const int first = a.Tk & 63, last = ((a.Tk + 7) & ~7) & 63;      // key columns inside the last tile
+        if ((a.Tk & 7) == 0) return;
+        h16 *vs = smem + ((nt - 1) % NS) * STAGE_H + KH;
+        for (int r = tid; r < D; r += 256) {
+            const int sw = (r >> 1) & 7;
+            for (int c = first; c < (last == 0 ? 64 : last); ++c) vs[r * 64 + ((((c >> 3) ^ sw)) << 3) + (c & 7)] = (h16)0.0f;
+        }
+        __syncthreads();
+    };
+
+    __syncthreads();                                                      // static LDS content in place before any DMA lands
+    // prologue: NS-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) issue();
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int kt = 0;
+    if (NS - 1 < nt) {                     // tile 0 with a refill behind it
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+        compute(0, T_{}, F_{});
+        kt = 1;
+    }
+    for (; kt + (NS - 1) < nt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; everyone finished tile kt-1
+        issue();                           // refill the ring slot tile kt-1 occupied
+        compute(kt, F_{}, F_{});
+    }
+    // drain: no more refills.  (Waiting for everything costs nothing here: at most NS-1 short tiles remain.)
+    for (; kt < nt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt == nt - 1) {
+            scrub_last();
+            if (kt == 0) compute(kt, T_{}, T_{});
+            else compute(kt, F_{}, T_{});
+        } else if (kt == 0) {
+            compute(kt, T_{}, F_{});
+        } else {
+            compute(kt, F_{}, F_{});
+        }
+    }
+
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        float l;
+        if (Cf::ONES) {
+            // O^T row D (fragment D/16, lane group (D%16)/4, register D%4) holds the denominator of query li
+            l = __shfl(oacc[D / 16][qs][D % 4], ((D % 16) / 4) * 16 + li, 64);
+        } else {
+            l = lrow[qs];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
+        const float inv = 1.0f / l;
+        const int qr = q0 + qs * 16 + li;
+        if (qr >= a.Tq) continue;
+#pragma unroll
+        for (int ds = 0; ds < D16; ++ds) {
+            const int dc = ds * 16 + lg * 4;
+            if (dc >= D) continue;
+            h16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (h16)(oacc[ds][qs][r] * inv);
+            *reinterpret_cast<h16x4 *>(op + (long long)qr * a.ldo + dc) = o;
+        }
+    }
+}
+
+// 4 waves x (16 * QS) queries; 2 blocks per CU (d <= 80: ring <= 68 KB) -> two waves per SIMD from DIFFERENT blocks, whose
+// MFMA and softmax phases drift apart and overlap.  The occupancy hint also keeps the accumulators out of the AGPR file.
+template <int D, int QS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void flash_ring_kernel(FARArgs a) {
+    flash_ring_body<D, QS>(a);
+}
+
+template <int D, int QS>
+static int launch_far_q(const FARArgs &a, hipStream_t s) {
+    using Cf = FARCfg<D>;
+    static bool attr_done = false;
+    if (Cf::LDS > 65536 && !attr_done) {
+        if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
+            attr_done = true;
+        else
+            (void)hipGetLastError();
+    }
+    dim3 grid((a.Tq + 64 * QS - 1) / (64 * QS), a.H, a.B);
+    hipLaunchKernelGGL((flash_ring_kernel<D, QS>), grid, dim3(256), Cf::LDS, s, a);
+    return L2D_OK;
+}
+
+template <int D>
+static int launch_far(const FARArgs &a, int qs, hipStream_t s) {
+    if (qs == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
+        const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
+        qs = (big >= 384) ? 2 : 1;
+    }
+    return qs == 2 ? launch_far_q<D, 2>(a, s) : launch_far_q<D, 1>(a, s);
+}
+
+// called from l2d_launch_flash_attn (flash_attn.hip) after argument validation
+int l2d_launch_flash_ring(const l2d_op *op, int qs, hipStream_t s) {
+    FARArgs a;
+    a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
+    a.zero = (const h16 *)op->p[4];
+    a.B = op->i[0]; a.H = op->i[1]; a.d = op->i[2]; a.Tq = op->i[3]; a.Tk = op->i[4];
+    a.ldq = op->i[5]; a.ldk = op->i[6]; a.ldvt = op->i[7]; a.ldo = op->i[8];
+    a.sq = op->l[0]; a.sk = op->l[1]; a.svt = op->l[2]; a.so = op->l[3];
+    switch (a.d) {
+        case 8: return launch_far<8>(a, qs, s);
+        case 16: return launch_far<16>(a, qs, s);
+        case 32: return launch_far<32>(a, qs, s);
+        case 40: return launch_far<40>(a, qs, s);
+        case 80: return launch_far<80>(a, qs, s);
+        case 160: return launch_far<160>(a, qs, s);
+    }
+    return L2D_EINVAL;
+}

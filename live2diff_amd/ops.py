@@ -192,17 +192,24 @@ def layernorm(x, gamma, beta, out, *, rows, C, ldx, ldo, eps=1e-5):
     return op, (x, gamma, beta, out)
 
 
-def flash_attn(q, k, vt, out, *, B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, q_off=0, k_off=0, vt_off=0):
+def flash_attn(q, k, vt, out, *, B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, q_off=0, k_off=0, vt_off=0,
+               variant=None):
+    """variant: 0 auto (LDS-DMA ring kernel), 1 register-staged kernel (round 1), 2 / 3 ring with 32 / 16 query rows per
+    wave; None = L2D_FLASH_VARIANT from the environment (A/B knob), default 0."""
     op = L2dOp()
     op.kind = _lib.OP_FLASH_ATTN
+    zp = zero_page(q.device)
     op.p[0] = _ptr(_h(q)) + q_off * 2
     op.p[1] = _ptr(_h(k)) + k_off * 2
     op.p[2] = _ptr(_h(vt)) + vt_off * 2
     op.p[3] = _ptr(_h(out))
-    for j, v in enumerate([B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo]):
+    op.p[4] = _ptr(zp)
+    if variant is None:
+        variant = int(os.environ.get("L2D_FLASH_VARIANT", "0"))
+    for j, v in enumerate([B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, variant]):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sq), int(sk), int(svt), int(so)
-    return op, (q, k, vt, out)
+    return op, (q, k, vt, out, zp)
 
 
 def tattn_stream(qkv, cache, q_pe, k_pe, v_pe, pe_idx, update_idx, bias, out, *, N, T, C, L, H, variant=0):
