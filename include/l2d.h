@@ -94,6 +94,8 @@ enum {
  * L2D_OP_TIMESTEP_EMBED  p0 timesteps (int64 [N]) p1 out half [N][dim]; i0 N i1 dim
  * L2D_OP_NCHW_TO_NHWC  p0 in half [B][C][HW] p1 out half [B][HW][Cpad]; i0 B i1 C i2 HW i3 Cpad
  * L2D_OP_NHWC_TO_NCHW  p0 in half [B][HW][ld] p1 out half [B][C][HW]; i0 B i1 C i2 HW i3 ld
+ *   both: i4 element map, fp16 rounding after each step: 0 copy, 1 (x + f1) * f0, 2 tanh(x / 3) * 3, 3 x * f0 + f1
+ *   (the input / output scalings of diffusers' EncoderTiny / DecoderTiny, reference swap point wrapper.py:468-470)
  * L2D_OP_LCM_STEP   x0 = c_out*(x - beta*eps)/alpha + c_skip*x  (reference pipeline :387-401)
  *   p0 x p1 eps p2 scal float [N][4]={alpha,beta,c_skip,c_out} p3 x0 ; i0 N i1 per_sample_elems
  * L2D_OP_COPY       p0 src p1 dst ; l0 bytes   (device-to-device, on the stream)
@@ -109,6 +111,14 @@ enum {
  *   i0 N (<= 8) i1 per (elements per row)
  * L2D_OP_RANDN      p0 out [n] half, standard normal (Philox4x32-10 + Box-Muller) p1 frame counter uint64* or 0
  *   l0 n l1 seed l2 offset (in Philox blocks of 4); element i = normal i%4 of block offset + frame*ceil(n/4) + i/4
+ *
+ * Depth-path glue (glue.hip; reference pipeline_stream_animation_depth.py:553,560-567):
+ * L2D_OP_RESIZE_BILINEAR  F.interpolate(mode="bilinear", align_corners=False) on fp16 planes:
+ *   p0 in [planes][Hin][Win] half p1 out [planes][Hout][Wout] half ; i0 planes i1 Hin i2 Win i3 Hout i4 Wout
+ * L2D_OP_MINMAX  min and max of a fp16 tensor, left on the device: p0 x half (16-byte aligned) p1 scratch float [2*nb]
+ *   p2 out float[2] = {min, max} ; l0 n ; i0 nb (blocks of the partial pass, <= 1024)
+ * L2D_OP_DEPTH_NORM_RESIZE  ((d - min) / (max - min)) -> 3 channels -> * 2 - 1 -> bilinear resize, fp16 rounding after each
+ *   reference tensor op:  p0 depth [B][Hd][Wd] half p1 {min, max} float[2] p2 out [B][3][H][W] half ; i0 B i1 Hd i2 Wd i3 H i4 W
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -127,6 +137,9 @@ enum {
     L2D_OP_RING_UPDATE = 14,
     L2D_OP_STREAM_SHIFT = 15,
     L2D_OP_RANDN = 16,
+    L2D_OP_RESIZE_BILINEAR = 17,
+    L2D_OP_MINMAX = 18,
+    L2D_OP_DEPTH_NORM_RESIZE = 19,
 };
 
 typedef struct l2d_op {

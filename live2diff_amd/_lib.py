@@ -18,6 +18,7 @@ OP_IGEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_FLASH_ATTN = 1, 2, 3, 4, 5
 OP_TATTN_STREAM, OP_TATTN_WARMUP, OP_SKINNY_LINEAR, OP_TIMESTEP_EMBED = 6, 7, 8, 9
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_LCM_STEP, OP_COPY = 10, 11, 12, 13
 OP_RING_UPDATE, OP_STREAM_SHIFT, OP_RANDN = 14, 15, 16
+OP_RESIZE_BILINEAR, OP_MINMAX, OP_DEPTH_NORM_RESIZE = 17, 18, 19
 ABI_VERSION = 1
 
 

@@ -45,6 +45,9 @@ static int run_one(const l2d_op *op, hipStream_t s) {
         case L2D_OP_RING_UPDATE: return l2d_launch_ring_update(op, s);
         case L2D_OP_STREAM_SHIFT: return l2d_launch_stream_shift(op, s);
         case L2D_OP_RANDN: return l2d_launch_randn(op, s);
+        case L2D_OP_RESIZE_BILINEAR: return l2d_launch_resize_bilinear(op, s);
+        case L2D_OP_MINMAX: return l2d_launch_minmax(op, s);
+        case L2D_OP_DEPTH_NORM_RESIZE: return l2d_launch_depth_norm_resize(op, s);
         case L2D_OP_COPY: {
             if (!op->p[0] || !op->p[1] || op->l[0] <= 0) {
                 l2d_set_error("copy(tag %d): invalid arguments", op->tag);

@@ -36,6 +36,9 @@ int l2d_launch_lcm_step(const l2d_op *op, hipStream_t s);
 int l2d_launch_ring_update(const l2d_op *op, hipStream_t s);
 int l2d_launch_stream_shift(const l2d_op *op, hipStream_t s);
 int l2d_launch_randn(const l2d_op *op, hipStream_t s);
+int l2d_launch_resize_bilinear(const l2d_op *op, hipStream_t s);
+int l2d_launch_minmax(const l2d_op *op, hipStream_t s);
+int l2d_launch_depth_norm_resize(const l2d_op *op, hipStream_t s);
 
 #ifdef __HIPCC__
 // SiLU / GELU are evaluated per output element inside GEMM epilogues and the GroupNorm apply pass (tens of millions of

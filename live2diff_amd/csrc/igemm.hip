@@ -65,7 +65,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
             if (a.bias) y += a.bias[n + r];
             if (rb) y += rb[n + r];
             if (a.epi == 2) y = l2d_silu(y);
+            if (a.epi == 3) y = fmaxf(y, 0.f);
             if (resp) y += (float)resp[(long long)m * a.ldr + n + r];
+            if (a.epi == 4) y = fmaxf(y, 0.f);
             outp[(long long)m * a.ldo + n + r] = (h16)y;
         }
         return;
@@ -76,10 +78,18 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = l2d_silu(v[r]);
     }
+    if (a.epi == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
     if (resp) {
         h16x4 rr = *reinterpret_cast<const h16x4 *>(resp + (long long)m * a.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+    }
+    if (a.epi == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
     h16x4 o;
 #pragma unroll
@@ -425,6 +435,10 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_ke
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = l2d_silu(v[r]);
                     }
+                    if (a.epi == 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
                     h16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
@@ -454,6 +468,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_ke
             if (m >= a.M || n >= NoutO) continue;
             h16x8 v = l2d_ld8(ot + row * pitch + cc * 8);
             if (resp) v = v + (RES_EARLY ? resv[RES_EARLY ? it : 0] : rlate[RES_EARLY ? 0 : it]);
+            if (a.epi == 4) v = __builtin_elementwise_max(v, l2d_zero8());          // relu(conv + skip), TAESD blocks
             l2d_st8(outp + (long long)m * a.ldo + n, v);
         }
         return;
@@ -578,7 +593,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
-        (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
+        a.epi < 0 || a.epi > 4 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 9 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);

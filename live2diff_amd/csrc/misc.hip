@@ -89,51 +89,63 @@ int l2d_launch_skinny_linear(const l2d_op *op, hipStream_t s) {
     return l2d_check_launch("skinny_linear", op->tag);
 }
 
-__global__ void nchw_to_nhwc_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int Cpad) {
+// mode 0: copy; 1: (x + b) * a (TAESD encoder input, x.add(1).div(2)); 2: tanh(x / 3) * 3 (TAESD decoder input);
+// 3: x * a + b (TAESD decoder output, x.mul(2).sub(1)).  Each step rounds to fp16 like the reference's fp16 tensor ops.
+__device__ __forceinline__ h16 l2d_layout_map(h16 x, int mode, float a, float b) {
+    if (mode == 1) return (h16)((float)(h16)((float)x + b) * a);
+    if (mode == 2) return (h16)((float)(h16)tanhf((float)(h16)((float)x * (1.0f / 3.0f))) * 3.0f);
+    if (mode == 3) return (h16)((float)(h16)((float)x * a) + b);
+    return x;
+}
+
+// One thread per output pixel: Cpad (8) halfs = one 16-byte store; the C plane reads are coalesced across threads.
+__global__ void nchw_to_nhwc_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int Cpad, int mode,
+                                    float a, float b) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)B * HW * Cpad;
     if (idx >= total) return;
     int c = (int)(idx % Cpad);
     long long pix = idx / Cpad;
-    int b = (int)(pix / HW);
-    int hw = (int)(pix - (long long)b * HW);
-    out[idx] = (c < C) ? in[((long long)b * C + c) * HW + hw] : (h16)0.0f;
+    int bb = (int)(pix / HW);
+    int hw = (int)(pix - (long long)bb * HW);
+    out[idx] = (c < C) ? l2d_layout_map(in[((long long)bb * C + c) * HW + hw], mode, a, b) : (h16)0.0f;
 }
 
-__global__ void nhwc_to_nchw_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int ld) {
+__global__ void nhwc_to_nchw_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int C, int HW, int ld, int mode, float a,
+                                    float b) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)B * C * HW;
     if (idx >= total) return;
     int hw = (int)(idx % HW);
     long long bc = idx / HW;
     int c = (int)(bc % C);
-    int b = (int)(bc / C);
-    out[idx] = in[((long long)b * HW + hw) * ld + c];
+    int bb = (int)(bc / C);
+    out[idx] = l2d_layout_map(in[((long long)bb * HW + hw) * ld + c], mode, a, b);
 }
 
 int l2d_launch_nchw_to_nhwc(const l2d_op *op, hipStream_t s) {
-    int B = op->i[0], C = op->i[1], HW = op->i[2], Cpad = op->i[3];
-    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) {
+    int B = op->i[0], C = op->i[1], HW = op->i[2], Cpad = op->i[3], mode = op->i[4];
+    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || Cpad < C || mode < 0 || mode > 3) {
         l2d_set_error("nchw_to_nhwc(tag %d): invalid arguments", op->tag);
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
     long long total = (long long)B * HW * Cpad;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0],
-                       (h16 *)op->p[1], B, C, HW, Cpad);
+                       (h16 *)op->p[1], B, C, HW, Cpad, mode, op->f[0], op->f[1]);
     return l2d_check_launch("nchw_to_nhwc", op->tag);
 }
 
 int l2d_launch_nhwc_to_nchw(const l2d_op *op, hipStream_t s) {
-    int B = op->i[0], C = op->i[1], HW = op->i[2], ld = op->i[3];
-    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || ld < C) {
+    int B = op->i[0], C = op->i[1], HW = op->i[2], ld = op->i[3], mode = op->i[4];
+    if (!op->p[0] || !op->p[1] || B <= 0 || C <= 0 || HW <= 0 || ld < C || mode < 0 || mode > 3) {
         l2d_set_error("nhwc_to_nchw(tag %d): invalid arguments", op->tag);
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
     long long total = (long long)B * C * HW;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0],
-                       (h16 *)op->p[1], B, C, HW, ld);
+                       (h16 *)op->p[1], B, C, HW, ld, mode, op->f[0], op->f[1]);
     return l2d_check_launch("nhwc_to_nchw", op->tag);
 }
 

@@ -101,6 +101,9 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, tap
     cdiv = lambda a, b: (a + b - 1) // b
     nk64 = Kp // 64
     big = cdiv(Nout, 128) * cdiv(M, 128) * batch
+    if Nout <= 64 and M >= 16384:
+        # narrow outputs (TAESD: 64 channels everywhere, 3 / 4 at the ends): a 128-wide channel tile would be half empty
+        return 2, 1, (v_small if nk64 <= 18 else 2)
     if big >= 384:
         return 1, 1, (4 if big >= 768 else v_big)
     if epi == 1:
@@ -257,22 +260,59 @@ def timestep_embed(t, out, *, N, dim):
     return op, (t, out)
 
 
-def nchw_to_nhwc(x, out, *, B, C, HW, Cpad):
+MAP_COPY, MAP_ADD_SCALE, MAP_TANH3, MAP_SCALE_ADD = 0, 1, 2, 3     # element maps of the layout kernels (include/l2d.h)
+
+
+def nchw_to_nhwc(x, out, *, B, C, HW, Cpad, mode=MAP_COPY, a=1.0, b=0.0):
     op = L2dOp()
     op.kind = _lib.OP_NCHW_TO_NHWC
     op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
-    for j, v in enumerate([B, C, HW, Cpad]):
+    for j, v in enumerate([B, C, HW, Cpad, mode]):
         op.i[j] = int(v)
+    op.f[0], op.f[1] = float(a), float(b)
     return op, (x, out)
 
 
-def nhwc_to_nchw(x, out, *, B, C, HW, ld):
+def nhwc_to_nchw(x, out, *, B, C, HW, ld, mode=MAP_COPY, a=1.0, b=0.0):
     op = L2dOp()
     op.kind = _lib.OP_NHWC_TO_NCHW
     op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
-    for j, v in enumerate([B, C, HW, ld]):
+    for j, v in enumerate([B, C, HW, ld, mode]):
+        op.i[j] = int(v)
+    op.f[0], op.f[1] = float(a), float(b)
+    return op, (x, out)
+
+
+def resize_bilinear(x, out, *, planes, Hin, Win, Hout, Wout):
+    """F.interpolate(x, (Hout, Wout), mode="bilinear", align_corners=False) on [planes, Hin, Win] fp16."""
+    op = L2dOp()
+    op.kind = _lib.OP_RESIZE_BILINEAR
+    op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
+    for j, v in enumerate([planes, Hin, Win, Hout, Wout]):
         op.i[j] = int(v)
     return op, (x, out)
+
+
+def minmax(x, scratch, out, *, n, nb=256):
+    """{min, max} of the first n halfs of x -> out float[2] on the device; scratch float[2*nb]."""
+    assert scratch.dtype == torch.float32 and scratch.numel() >= 2 * nb and out.dtype == torch.float32 and out.numel() >= 2
+    op = L2dOp()
+    op.kind = _lib.OP_MINMAX
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x)), _ptr(scratch), _ptr(out)
+    op.l[0] = int(n)
+    op.i[0] = int(nb)
+    return op, (x, scratch, out)
+
+
+def depth_norm_resize(depth, mm, out, *, B, Hd, Wd, H, W):
+    """reference pipeline_stream_animation_depth.py:560-567 in one pass: depth [B,Hd,Wd] fp16 + {min,max} -> [B,3,H,W] fp16."""
+    assert mm.dtype == torch.float32
+    op = L2dOp()
+    op.kind = _lib.OP_DEPTH_NORM_RESIZE
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(depth)), _ptr(mm), _ptr(_h(out))
+    for j, v in enumerate([B, Hd, Wd, H, W]):
+        op.i[j] = int(v)
+    return op, (depth, mm, out)
 
 
 def lcm_step(x, eps, scal, x0, *, N, per):

@@ -140,6 +140,7 @@ class StreamAnimateDiffusionDepth:
         self.unet = pipe.unet                       # HipStreamingUNet (or anything with the same call contract)
         self.vae = getattr(pipe, "vae", None)
         self.depth_detector = getattr(pipe, "depth_model", None)
+        self._depth_glue, self._glue_off = None, False      # HipDepthGlue, created on first use on the device
         self.inference_time_ema = 0
         self.depth_time_ema = 0
         self.inference_time_list = []
@@ -147,6 +148,15 @@ class StreamAnimateDiffusionDepth:
         self.mask_shift = 1
         self.is_tensorrt = False
         self.unet_warmup = None
+
+    @property
+    def depth_glue(self):
+        return self._depth_glue
+
+    @depth_glue.setter
+    def depth_glue(self, g):
+        """assign a HipDepthGlue, or None to use the reference's torch expressions (comparison runs)"""
+        self._depth_glue, self._glue_off = g, g is None
 
     # ------------------------------------------------------------------ cache / timesteps / lora
     def prepare_cache(self, height, width, denoising_steps_num):
@@ -308,13 +318,25 @@ class StreamAnimateDiffusionDepth:
         return out.clip(-1, 1)
 
     def encode_depth(self, image_tensors):
+        """reference :544-571.  On the device the arithmetic around the (caller-owned) depth detector -- the 384x384 bilinear
+        resize, the min-max normalisation over the batch, x3 channels, [-1,1], the resize back -- runs as HIP ops without the
+        reference's two host-visible reductions (`self.depth_glue`, vae_hip.HipDepthGlue); CPU tensors (host-logic tests)
+        and `depth_glue = None` take the reference's torch expressions."""
         image_tensors = image_tensors.to(device=self.device, dtype=self.depth_detector.dtype)
         h, w = image_tensors.shape[2], image_tensors.shape[3]
-        images_input = F.interpolate(image_tensors, (384, 384), mode="bilinear", align_corners=False)
-        depth_map = self.depth_detector(images_input)
-        dn = (depth_map - depth_map.min()) / (depth_map.max() - depth_map.min())
-        dn = dn[:, None].repeat(1, 3, 1, 1) * 2 - 1
-        dn = F.interpolate(dn, (h, w), mode="bilinear", align_corners=False)
+        glue = self.depth_glue
+        if glue is None and image_tensors.is_cuda and image_tensors.dtype == torch.float16 and not self._glue_off:
+            from .vae_hip import HipDepthGlue
+            glue = self.depth_glue = HipDepthGlue(self.device)
+        if glue is not None:
+            depth_map = self.depth_detector(glue.resize(image_tensors, 384, 384))
+            dn = glue.normalize_resize(depth_map.to(torch.float16), h, w)
+        else:
+            images_input = F.interpolate(image_tensors, (384, 384), mode="bilinear", align_corners=False)
+            depth_map = self.depth_detector(images_input)
+            dn = (depth_map - depth_map.min()) / (depth_map.max() - depth_map.min())
+            dn = dn[:, None].repeat(1, 3, 1, 1) * 2 - 1
+            dn = F.interpolate(dn, (h, w), mode="bilinear", align_corners=False)
         return retrieve_latents(self.vae.encode(dn.to(dtype=self.vae.dtype)), self.generator) * self.vae.config.scaling_factor
 
     def enable_device_step(self, use_graph: bool = False, seed: int = 0):

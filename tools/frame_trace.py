@@ -19,6 +19,8 @@ FAMILIES = ("igemm_splitk_epilogue", "igemm_kernel", "gn_stats_kernel", "gn_appl
 
 
 def family(name):
+    if "flash_ring_kernel" in name:            # the LDS-DMA ring build of the same plan op (flash_attn_ring.hip)
+        return "flash_attn_kernel"
     for f in FAMILIES:
         if f in name:
             return "tattn_stream_kernel" if f == "tattn_stream" else f

@@ -13,20 +13,17 @@ import json
 import sqlite3
 import sys
 
-PRODUCT = ("igemm", "gn_", "layernorm", "flash_attn", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step")
+PRODUCT = ("igemm", "gn_", "layernorm", "flash_attn", "flash_ring", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step")
 
 
 def short(name):
+    """kernel name with its template arguments kept (flash_ring_kernel<40, 2> and <80, 1> are different kernels)"""
     n = name.replace("void ", "").split("(")[0]
-    if n.startswith("_Z"):
-        for p in PRODUCT:
-            if p in n:
-                return p.rstrip("_") + "_kernel" if not p.endswith("kernel") else p
     return n
 
 
 def family(name):
-    for p in ("igemm_splitk_epilogue", "igemm_kernel", "gn_stats", "gn_apply", "layernorm", "flash_attn", "tattn_stream", "tattn_warmup",
+    for p in ("igemm_splitk_epilogue", "igemm_kernel", "gn_stats", "gn_apply", "layernorm", "flash_attn", "flash_ring", "tattn_stream", "tattn_warmup",
               "skinny_linear", "timestep_embed", "nchw_to_nhwc", "nhwc_to_nchw", "lcm_step"):
         if p in name:
             return p + ("_kernel" if not p.endswith("kernel") and p != "igemm_splitk_epilogue" else "")

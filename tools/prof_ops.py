@@ -63,6 +63,17 @@ def main():
     for _ in range(REPS):
         run(ops.flash_attn(qk, qk, vt, fo, B=N, H=Hh, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=T, ldo=C, sq=T * 2 * C,
                            sk=T * 2 * C, svt=C * T, so=T * C, k_off=C))
+    # --- flash attention, the other frame shapes: d=80 T=1024, d=160 T=256, text cross-attention d=40 4096x77
+    for (dd, TT, Tk) in ((80, 1024, 1024), (160, 256, 256), (40, 4096, 77)):
+        CC = 8 * dd
+        q_ = rn(N * TT, CC)
+        k_ = rn(N * Tk, CC)
+        ld = (Tk + 7) // 8 * 8
+        vt_ = rn(N, CC, ld)
+        o_ = torch.empty(N * TT, CC, dtype=torch.float16, device=DEV)
+        for _ in range(REPS):
+            run(ops.flash_attn(q_, k_, vt_, o_, B=N, H=8, d=dd, Tq=TT, Tk=Tk, ldq=CC, ldk=CC, ldvt=ld, ldo=CC, sq=TT * CC, sk=Tk * CC,
+                               svt=CC * ld, so=TT * CC))
     # --- GroupNorm level 0
     gm, bt = torch.ones(C, dtype=torch.float16, device=DEV), torch.zeros(C, dtype=torch.float16, device=DEV)
     part = torch.empty(2 * 128 * 32 * 2, dtype=torch.float32, device=DEV)
