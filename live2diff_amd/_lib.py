@@ -55,6 +55,8 @@ def _load():
                                  ctypes.POINTER(ctypes.c_float)]
     lib.l2d_copy_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.POINTER(ctypes.c_float)]
+    lib.l2d_read_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     if lib.l2d_abi_version() != ABI_VERSION:
         raise L2DError(f"libl2d_hip.so ABI {lib.l2d_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     return lib

@@ -16,7 +16,7 @@
 //     applied on the SOURCE side instead (a lane fetches the logical 16-byte slot  p ^ swz(row)  of its row) and again on the
 //     fragment reads.  K is kept as KK sub-tiles of [64 keys][32 halfs] (64-byte rows, slot ^ ((row>>1)&3): the igemm BK = 32
 //     image, conflict-free for the ds_read_b128 lane groups); V^T as [d rows][64 keys] (128-byte rows, slot ^ ((row>>1)&7):
-//     conflict-free for the two 8-byte reads per fragment).  Zero padding (d = 40 -> 64 in QK^T, -> 48 rows in PV) and the
+//     conflict-free for the 16-byte fragment reads).  Zero padding (d = 40 -> 64 in QK^T, -> 48 rows in PV) and the
 //     row of ones that yields the softmax denominator on the matrix cores are written ONCE per ring slot; the DMA never
 //     touches them (exec-masked lanes), so padding costs no memory traffic.
 //   * Softmax: Q is pre-scaled by log2(e)/sqrt(d) when it is loaded (fp16, one more rounding of the size Q already
@@ -24,7 +24,14 @@
 //     s*c - m: a probability is ONE v_exp_f32 (the old kernel: FMA + exp).  The reference is only raised -- and O, l rescaled,
 //     in a wave-uniform branch, with the pending tile's scores adjusted before they are exponentiated -- when some row
 //     exceeds it by more than 2^8 (p <= 256 is harmless in fp16; O, l are fp32).
+//   * Key order inside a tile is free as long as K rows and V^T columns agree.  The S^T accumulator gives lane group g the
+//     tile rows {16 ks + 4 g + r}; the K rows are therefore DMA'd in the permuted order  row 32c + 16h + 4g + r <- key
+//     32c + 8g + 4h + r, which makes the 8 keys a lane needs for one PV MFMA CONTIGUOUS in V^T: one conflict-free
+//     ds_read_b128 per fragment instead of two 8-byte reads (which hipcc fused into ds_read2st64_b64: half rate and 2-way
+//     bank conflicts -- 30 % of the LDS cycles of the first version of this kernel, PMC pass profiles/r2d_pmc_ops.txt).
 //   * Query rows per wave are a template parameter (32 or 16): levels with few queries (T <= 1024) get twice the blocks.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -35,7 +42,7 @@
 struct FARArgs {
     const h16 *q, *k, *vt, *zero;
     h16 *out;
-    int B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo;
+    int B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, xcd;
     long long sq, sk, svt, so;
 };
 
@@ -74,8 +81,19 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
+    // XCD-aware block order.  Blocks are dispatched round-robin over the 8 XCDs (private L2s): with (q-block, head, batch)
+    // as a plain 3-D grid every XCD would see the K / V of EVERY head (10.5 MB at cfg-2, 32 q-blocks re-reading each head's
+    // 655 KB) and thrash its 4 MB L2.  The 1-D grid is remapped (bijectively) so that each XCD runs a contiguous range of
+    // (batch, head, q-block): the q-blocks of a head share one L2, which then holds just ~2 heads.
+    const int nqb = (a.Tq + 64 * QS - 1) / (64 * QS);
+    int wgid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wgid = a.xcd ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : (int)blockIdx.x;
+    }
+    const int bh = wgid / nqb, qb = wgid - bh * nqb;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int q0 = qb * (64 * QS) + wave * (16 * QS);
     const h16 *qp = a.q + (long long)b * a.sq + h * D;
     const h16 *kp = a.k + (long long)b * a.sk + h * D;
     const h16 *vp = a.vt + (long long)b * a.svt + (long long)h * D * a.ldvt;
@@ -114,6 +132,8 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     // ---- DMA descriptors (tile-invariant parts).  K sub-tile kk: this wave fills rows 16w .. 16w+15, lane l = (row l>>2, physical slot l&3).
     const int krow = wave * 16 + (lane >> 2);
     const int kcol = (((lane & 3) ^ ((krow >> 1) & 3)) << 3);             // logical column (halfs) inside the sub-tile
+    // tile row krow = 32c + 16h + 4g + r holds key 32c + 8g + 4h + r (see the header): PV fragments become 16-byte reads
+    const int kkey = (krow & 32) | (((krow >> 2) & 3) << 3) | (((krow >> 4) & 1) << 2) | (krow & 3);
     // V^T: wave-instruction j fills rows 8j .. 8j+7, lane l = (row l>>3, physical slot l&7); this wave owns j = wave, wave+4, ...
     int vrow[VPW], vkey[VPW];
 #pragma unroll
@@ -123,28 +143,34 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         vkey[i] = (((lane & 7) ^ ((vrow[i] >> 1) & 7)) << 3);             // first key (within the tile) of the logical slot
     }
     h16 *dummy = smem + NS * STAGE_H;
+    // per-lane source pointers of tile 0; a tile step is a constant stride (no 64-bit multiplies in the loop)
+    const h16 *kptr = kp + (long long)kkey * a.ldk + kcol;               // + kk * 32
+    const long long kstep = 64ll * a.ldk;
+    const h16 *vptr[VPW];
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) vptr[i] = vp + (long long)vrow[i] * a.ldvt + vkey[i];
 
     int is_slot = 0, is_key0 = 0;
     auto issue = [&]() {                                                  // LPS DMA wave-instructions, always
         h16 *st = smem + is_slot * STAGE_H;
-        const int key = is_key0 + krow;
+        const bool kin = (is_key0 + kkey) < a.Tk;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const int col = kk * 32 + kcol;
-            if (col < D) {                                                // padding columns stay zero: lane masked off
-                const h16 *src = (key < a.Tk) ? kp + (long long)key * a.ldk + col : a.zero;
+            if (kk * 32 + kcol < D) {                                     // padding columns stay zero: lane masked off
+                const h16 *src = kin ? kptr + kk * 32 : a.zero;
                 __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + kk * 2048 + wave * 512), 16, 0, 0);
             }
         }
+        kptr += kstep;
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
             const int j = wave + 4 * i;                                   // wave-uniform
             if (j < NVI) {
                 if (vrow[i] < D) {
-                    const int key = is_key0 + vkey[i];
-                    const h16 *src = (key < a.Tk) ? vp + (long long)vrow[i] * a.ldvt + key : a.zero;
+                    const h16 *src = (is_key0 + vkey[i] < a.Tk) ? vptr[i] : a.zero;
                     __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + KH + j * 512), 16, 0, 0);
                 }
+                vptr[i] += 64;
             } else {
                 __builtin_amdgcn_global_load_lds(L2D_GPTR(a.zero), L2D_LPTR(dummy), 16, 0, 0);   // keeps vmcnt bookkeeping uniform
             }
@@ -156,12 +182,9 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     // fragment read offsets (halfs, relative to the stage base); the swizzle terms are tile- and block-row-invariant
     const int kswz = (li >> 1) & 3, vswz = (li >> 1) & 7;
     const int koff = li * 32 + ((lg ^ kswz) << 3);                        // + kk*2048 + ks*512
-    int voff[2][2];                                                       // [c2][half]: + ds*1024
+    int voff[2];                                                          // [c2]: + ds*1024; keys 32 c2 + 8 lg .. + 7
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-            voff[c2][hh] = KH + li * 64 + (((c2 * 4 + (lg >> 1) + 2 * hh) ^ vswz) << 3) + (lg & 1) * 4;
+    for (int c2 = 0; c2 < 2; ++c2) voff[c2] = KH + li * 64 + (((c2 * 4 + lg) ^ vswz) << 3);
 
     f32x4 oacc[D16][QS];
 #pragma unroll
@@ -179,16 +202,40 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     auto compute = [&](int kt, auto first_tag, auto last_tag) {
         constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
         const h16 *st = smem + cp_slot * STAGE_H;
+        // Instruction order is chosen so that ONE wave keeps both pipes busy (the matrix pipe executes an MFMA for 16
+        // cycles after a 4-cycle issue; independent VALU work issued behind it runs in its shadow): q-subtile-major QK^T
+        // (row maximum of subtile 0 under the MFMAs of subtile 1), one rescale decision for both subtiles (a single rarely
+        // taken branch instead of two basic-block boundaries), then exp / pack of subtile 1 under the PV MFMAs of subtile 0.
+        // (The subtile-major order holds all K / V^T fragments of a tile in registers: 32 + 24 VGPRs at d = 40.  The wide
+        // heads would spill -- they keep the fragment-major order and rely on the second resident block for overlap.)
+        constexpr bool SUBTILE_MAJOR = (QS == 2 && KK <= 2 && D16 <= 3);
         f32x4 sacc[4][QS];
+        float mx[QS];
+        if (SUBTILE_MAJOR) {
+            h16x8 kf[KK][4];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
+            for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h16x8 kf = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
+                for (int ks = 0; ks < 4; ++ks) kf[kk][ks] = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
 #pragma unroll
-                for (int qs = 0; qs < QS; ++qs)
-                    sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qs][kk], kk == 0 ? cinit[qs] : sacc[ks][qs], 0, 0, 0);
+            for (int qs = 0; qs < QS; ++qs) {
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk][ks], qf[qs][kk], kk == 0 ? cinit[qs] : sacc[ks][qs], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h16x8 k1 = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs)
+                        sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qs][kk], kk == 0 ? cinit[qs] : sacc[ks][qs], 0, 0, 0);
+                }
+        }
         if (LAST && (kt + 1) * 64 > a.Tk) {                               // keys beyond Tk exist in the last tile only
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -196,20 +243,23 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((kt * 64 + ks * 16 + lg * 4 + r) >= a.Tk) sacc[ks][qs][r] = -3.0e38f;
+                        if ((kt * 64 + (ks >> 1) * 32 + lg * 8 + (ks & 1) * 4 + r) >= a.Tk) sacc[ks][qs][r] = -3.0e38f;
         }
-        h16x8 pf[2][QS];
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
-            float mx = fmaxf(fmaxf(sacc[0][qs][0], sacc[0][qs][1]), fmaxf(sacc[0][qs][2], sacc[0][qs][3]));
+            float m = fmaxf(fmaxf(sacc[0][qs][0], sacc[0][qs][1]), fmaxf(sacc[0][qs][2], sacc[0][qs][3]));
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks)
-                mx = fmaxf(fmaxf(mx, fmaxf(sacc[ks][qs][0], sacc[ks][qs][1])), fmaxf(sacc[ks][qs][2], sacc[ks][qs][3]));
-            mx = far_row_max(mx);
-            // sacc already is  s*c - mref.  Raise the reference (rarely after the first tile): everything still at the old
-            // reference -- O, l and THIS tile's not yet exponentiated scores -- is moved to the new one exactly once.
-            if (FIRST || __any(mx > 8.0f)) {
-                const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+                m = fmaxf(fmaxf(m, fmaxf(sacc[ks][qs][0], sacc[ks][qs][1])), fmaxf(sacc[ks][qs][2], sacc[ks][qs][3]));
+            mx[qs] = far_row_max(m);
+        }
+        // sacc already is  s*c - mref.  Raise the reference (rarely after the first tile): everything still at the old
+        // reference -- O, l and THIS tile's not yet exponentiated scores -- is moved to the new one exactly once.  A subtile
+        // whose maximum did not grow gets delta = 0, alpha = 1: the same code path, exact.
+        if (FIRST || __any((QS == 2 ? fmaxf(mx[0], mx[QS - 1]) : mx[0]) > 8.0f)) {
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+                const float delta = FIRST ? mx[qs] : fmaxf(mx[qs], 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);      // (first tile: O = l = 0, any finite alpha will do)
                 mref[qs] += delta;
                 lrow[qs] *= alpha;
@@ -219,6 +269,18 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 for (int ks = 0; ks < 4; ++ks) sacc[ks][qs] -= delta;
                 cinit[qs] = (f32x4){-mref[qs], -mref[qs], -mref[qs], -mref[qs]};
             }
+        }
+        constexpr bool VF_UP_FRONT = SUBTILE_MAJOR;                       // 8 * D16 VGPRs of V^T fragments held across both subtiles
+        h16x8 vf[2][VF_UP_FRONT ? D16 : 1];
+        if (VF_UP_FRONT) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) vf[c2][VF_UP_FRONT ? ds : 0] = l2d_ld8(st + ds * 1024 + voff[c2]);
+        }
+        h16x8 pf[2][QS];
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
             float psum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -229,18 +291,25 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                     pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
                 }
             if (!Cf::ONES) lrow[qs] += psum;
-        }
+            if (VF_UP_FRONT) {
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+                for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int ds = 0; ds < D16; ++ds) {
-                const h16x4 lo = *reinterpret_cast<const h16x4 *>(st + ds * 1024 + voff[c2][0]);
-                const h16x4 hi = *reinterpret_cast<const h16x4 *>(st + ds * 1024 + voff[c2][1]);
-                const h16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int qs = 0; qs < QS; ++qs)
-                    oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+                    for (int ds = 0; ds < D16; ++ds)
+                        oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][VF_UP_FRONT ? ds : 0], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
             }
+        }
+        if (!VF_UP_FRONT) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) {
+                    const h16x8 v1 = l2d_ld8(st + ds * 1024 + voff[c2]);
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs)
+                        oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+                }
+        }
         cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
     };
 
@@ -336,7 +405,7 @@ static int launch_far_q(const FARArgs &a, hipStream_t s) {
         else
             (void)hipGetLastError();
     }
-    dim3 grid((a.Tq + 64 * QS - 1) / (64 * QS), a.H, a.B);
+    dim3 grid(((a.Tq + 64 * QS - 1) / (64 * QS)) * a.H * a.B);      // 1-D: decoded XCD-aware in the kernel
     hipLaunchKernelGGL((flash_ring_kernel<D, QS>), grid, dim3(256), Cf::LDS, s, a);
     return L2D_OK;
 }
@@ -347,7 +416,10 @@ static int launch_far(const FARArgs &a, int qs, hipStream_t s) {
         const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
         qs = (big >= 384) ? 2 : 1;
     }
-    return qs == 2 ? launch_far_q<D, 2>(a, s) : launch_far_q<D, 1>(a, s);
+    if constexpr (D <= 80) {          // d = 160 with 32 query rows per wave does not fit the register file
+        if (qs == 2) return launch_far_q<D, 2>(a, s);
+    }
+    return launch_far_q<D, 1>(a, s);
 }
 
 // called from l2d_launch_flash_attn (flash_attn.hip) after argument validation
@@ -355,6 +427,12 @@ int l2d_launch_flash_ring(const l2d_op *op, int qs, hipStream_t s) {
     FARArgs a;
     a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
     a.zero = (const h16 *)op->p[4];
+    static int xcd_order = -1;          // A/B knob: L2D_FLASH_XCD=0 keeps the plain (q-block fastest) block order
+    if (xcd_order < 0) {
+        const char *e = getenv("L2D_FLASH_XCD");
+        xcd_order = (e && e[0] == '0') ? 0 : 1;
+    }
+    a.xcd = xcd_order;
     a.B = op->i[0]; a.H = op->i[1]; a.d = op->i[2]; a.Tq = op->i[3]; a.Tk = op->i[4];
     a.ldq = op->i[5]; a.ldk = op->i[6]; a.ldvt = op->i[7]; a.ldo = op->i[8];
     a.sq = op->l[0]; a.sk = op->l[1]; a.svt = op->l[2]; a.so = op->l[3];

@@ -176,9 +176,18 @@ int l2d_launch_lcm_step(const l2d_op *op, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------- HBM copy probe
+// float4 copy: 4 independent 16-byte loads in flight per thread, non-temporal stores (the written lines are not read again:
+// keeping them out of the L2 / Infinity Cache leaves those to the read stream)
 __global__ __launch_bounds__(256) void copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, long long n16) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
@@ -189,7 +198,7 @@ extern "C" int l2d_copy_bench(const void *src, void *dst, int64_t bytes, int rep
     }
     hipStream_t s = (hipStream_t)stream;
     long long n16 = bytes / 16;
-    int grid = 256 * 8;
+    int grid = 256 * 4;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);

@@ -26,7 +26,12 @@ def run(opk, variant=None):
     pl.run()
 
 
+ONLY = os.environ.get("L2D_PROF_ONLY", "")      # e.g. "flash": profile only the flash-attention launches
+
+
 def main():
+    if ONLY == "flash":
+        return flash_only()
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s: torch.randn(*s, generator=g, device=DEV, dtype=torch.float16)
     # --- conv 64x64 320->320 (level-0 resnet conv), 64x64 tile
@@ -84,6 +89,24 @@ def main():
         run(ops.gn_apply(x, part, gm, bt, go, eps=1e-5, silu=True, **kw))
     torch.cuda.synchronize()
     print("prof_ops done")
+
+
+def flash_only():
+    """self-attention of the three levels + the level-0 text cross-attention, one kernel name per shape where possible"""
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV, dtype=torch.float16)
+    N = 2
+    for (dd, TT, Tk) in ((40, 4096, 4096), (80, 1024, 1024), (160, 256, 256)):
+        CC = 8 * dd
+        q_, k_ = rn(N * TT, CC), rn(N * Tk, CC)
+        ld = (Tk + 7) // 8 * 8
+        vt_ = rn(N, CC, ld)
+        o_ = torch.empty(N * TT, CC, dtype=torch.float16, device=DEV)
+        for _ in range(REPS):
+            run(ops.flash_attn(q_, k_, vt_, o_, B=N, H=8, d=dd, Tq=TT, Tk=Tk, ldq=CC, ldk=CC, ldvt=ld, ldo=CC, sq=TT * CC, sk=Tk * CC,
+                               svt=CC * ld, so=TT * CC))
+    torch.cuda.synchronize()
+    print("prof_ops flash done")
 
 
 if __name__ == "__main__":
