@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 1
+#define L2D_ABI_VERSION 2
 
 enum {
     L2D_OK = 0,
@@ -56,13 +56,21 @@ enum {
  *   p7 16-byte zero page (padding source)   p8 split-K workspace [batch][S][M][round_up(Nout,4)] float
  *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch) i22 tile (0 auto, 1 = 128x128,
  *   2 = 64x64; + 16 = weight-tile-major block order: each XCD's L2 holds a band of output channels, for
- *   weight-dominated shapes; + 32 = direct register -> global epilogue (8-byte pieces) instead of the default one that
+ *   GroupNorm statistics of the OUTPUT, accumulated by the producer (replaces the consumer's L2D_OP_GN_STATS launch):
+ *   p9 / p10 accumulators int64 [samples][G][2] of up to two consumer GroupNorms, or 0 ; i24 T (tokens per sample)
+ *   i25 G ; i26 / i27 channels per group and channel offset of this tensor inside consumer 1's (concatenated) channel axis
+ *   i28 / i29 the same for consumer 2.  Sums are deterministic fixed-point atomics: sum x in units of 2^-20, sum x^2 in
+ *   units of 2^-12 (cannot overflow int64 for fp16 data at these sizes); the accumulators must be zero before the launch.
+ *   Needs the LDS-staged epilogue (Nout % 8 == 0 ...) or split-K, and tiles that do not straddle samples (T % 128 == 0,
+ *   or T % 64 == 0 with the 64x64 tile / split-K).
+ *   i22 also: + 32 = direct register -> global epilogue (8-byte pieces) instead of the default one that
  *   transposes the tile through LDS and stores whole rows with 16 bytes per lane) i23 pipeline variant (igemm.hip launch_p)
  *
  * L2D_OP_GN_STATS / L2D_OP_GN_APPLY   GroupNorm over channels-last [B,T,C1(+C2)] (two-input = concat),
  *                optional SiLU (reference: InflatedGroupNorm resnet.py:68-76, F.silu :233,249)
  *   p0 x1 p1 x2|0 p2 partial[B][nchunk][G][2] float  (apply: p3 gamma half, p4 beta half, p5 out half)
  *   i0 B i1 T i2 C1 i3 C2 i4 ld1 i5 ld2 i6 G i7 nchunk i8 silu  f0 eps
+ *   GN_APPLY with nchunk = 0: p6 = int64 [B][G][2] fixed-point accumulators filled by the producing igemm launches (above)
  *
  * L2D_OP_LAYERNORM  p0 x [rows][ld] p1 gamma p2 beta p3 out [rows][C] ; i0 rows i1 C i2 ldx i3 ldo; f0 eps
  *
@@ -145,8 +153,8 @@ enum {
 typedef struct l2d_op {
     int32_t kind;
     int32_t tag;          /* free for the host (plan index / layer id); echoed in error messages */
-    void *p[10];
-    int32_t i[24];
+    void *p[12];
+    int32_t i[32];
     int64_t l[4];
     float f[4];
 } l2d_op;

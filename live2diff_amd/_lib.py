@@ -19,7 +19,7 @@ OP_TATTN_STREAM, OP_TATTN_WARMUP, OP_SKINNY_LINEAR, OP_TIMESTEP_EMBED = 6, 7, 8,
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_LCM_STEP, OP_COPY = 10, 11, 12, 13
 OP_RING_UPDATE, OP_STREAM_SHIFT, OP_RANDN = 14, 15, 16
 OP_RESIZE_BILINEAR, OP_MINMAX, OP_DEPTH_NORM_RESIZE = 17, 18, 19
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class L2DError(RuntimeError):
@@ -30,8 +30,8 @@ class L2dOp(ctypes.Structure):
     _fields_ = [
         ("kind", ctypes.c_int32),
         ("tag", ctypes.c_int32),
-        ("p", ctypes.c_void_p * 10),
-        ("i", ctypes.c_int32 * 24),
+        ("p", ctypes.c_void_p * 12),
+        ("i", ctypes.c_int32 * 32),
         ("l", ctypes.c_int64 * 4),
         ("f", ctypes.c_float * 4),
     ]

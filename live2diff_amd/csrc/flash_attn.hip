@@ -264,8 +264,8 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     const int variant = op->i[9];   // 0 auto (LDS-DMA ring kernel when its alignment rules hold), 1 register-staged kernel,
-                                    // 2 / 3 ring kernel with 32 / 16 query rows per wave
-    if (variant < 0 || variant > 3) {
+                                    // 2 / 3 ring kernel with 32 / 16 query rows per wave, 4 = 8 waves x 16 rows, 5 = shallow ring
+    if (variant < 0 || variant > 5) {
         l2d_set_error("flash_attn(tag %d): unknown variant %d", op->tag, variant);
         return L2D_EINVAL;
     }
@@ -277,7 +277,7 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
     }
     L2D_DRY_RETURN();
     if (variant != 1 && ring_ok) {
-        int rc = l2d_launch_flash_ring(op, variant == 2 ? 2 : (variant == 3 ? 1 : 0), s);
+        int rc = l2d_launch_flash_ring(op, variant >= 2 ? variant : 0, s);
         if (rc != L2D_OK) {
             l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,80,160)", op->tag, a.d);
             return rc;

@@ -55,7 +55,7 @@ __device__ __forceinline__ float far_row_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D>
+template <int D, int NW = 4, int NSF = 0>     // NW waves per block (4 or 8); NSF forces the ring depth (0 = by LDS size)
 struct FARCfg {
     static constexpr int KK = (D + 31) / 32;              // [64][32] K sub-tiles (QK^T contraction steps)
     static constexpr int D16 = (D + 15) / 16;             // 16-row blocks of O^T
@@ -64,17 +64,20 @@ struct FARCfg {
     static constexpr int KBYTES = KK * 64 * 32 * 2;
     static constexpr int VBYTES = DV * 64 * 2;
     static constexpr int STAGE = KBYTES + VBYTES;         // bytes
-    static constexpr int NS = (STAGE * 4 <= 60 * 1024) ? 4 : 3;
+    static constexpr int NS = NSF ? NSF : ((STAGE * 4 <= 60 * 1024) ? 4 : 3);
+    static constexpr int NKI = KK * 4;                    // K DMA wave-instructions per tile (16 rows of one sub-tile each)
+    static constexpr int KPW = (NKI + NW - 1) / NW;       // ... per wave (waves without a real one issue a dummy)
     static constexpr int NVI = (D + 7) / 8;               // V^T DMA wave-instructions per tile (8 rows each)
-    static constexpr int VPW = (NVI + 3) / 4;             // ... per wave (waves without a real one issue a dummy)
-    static constexpr int LPS = KK + VPW;                  // DMA instructions per wave per stage
+    static constexpr int VPW = (NVI + NW - 1) / NW;       // ... per wave
+    static constexpr int LPS = KPW + VPW;                 // DMA instructions per wave per stage
     static constexpr int LDS = NS * STAGE + 1024;         // + 1 KB landing zone for the dummy DMAs
 };
 
-template <int D, int QS>
+template <int D, int QS, int NW, int NSF>
 __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
-    using Cf = FARCfg<D>;
+    using Cf = FARCfg<D, NW, NSF>;
     constexpr int KK = Cf::KK, D16 = Cf::D16, DV = Cf::DV, NS = Cf::NS, LPS = Cf::LPS, VPW = Cf::VPW, NVI = Cf::NVI;
+    constexpr int KPW = Cf::KPW, NKI = Cf::NKI, NT = 64 * NW;
     constexpr int STAGE_H = Cf::STAGE / 2, KH = Cf::KBYTES / 2;      // halfs
     extern __shared__ __attribute__((aligned(16))) h16 smem[];      // the ONLY LDS object: ring, then the dummy zone
 
@@ -85,7 +88,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     // as a plain 3-D grid every XCD would see the K / V of EVERY head (10.5 MB at cfg-2, 32 q-blocks re-reading each head's
     // 655 KB) and thrash its 4 MB L2.  The 1-D grid is remapped (bijectively) so that each XCD runs a contiguous range of
     // (batch, head, q-block): the q-blocks of a head share one L2, which then holds just ~2 heads.
-    const int nqb = (a.Tq + 64 * QS - 1) / (64 * QS);
+    const int nqb = (a.Tq + 16 * NW * QS - 1) / (16 * NW * QS);
     int wgid;
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     }
     const int bh = wgid / nqb, qb = wgid - bh * nqb;
     const int b = bh / a.H, h = bh - b * a.H;
-    const int q0 = qb * (64 * QS) + wave * (16 * QS);
+    const int q0 = qb * (16 * NW * QS) + wave * (16 * QS);
     const h16 *qp = a.q + (long long)b * a.sq + h * D;
     const h16 *kp = a.k + (long long)b * a.sk + h * D;
     const h16 *vp = a.vt + (long long)b * a.svt + (long long)h * D * a.ldvt;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     // ---- static LDS content, written once: zeros everywhere (QK^T / PV padding), ones in V^T row D of every stage
     {
         const h16x8 z = l2d_zero8();
-        for (int i = tid; i < (Cf::LDS / 16); i += 256) l2d_st8(smem + i * 8, z);
+        for (int i = tid; i < (Cf::LDS / 16); i += NT) l2d_st8(smem + i * 8, z);
         if (Cf::ONES) {
             __syncthreads();
             h16x8 one;
@@ -130,7 +133,9 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     }
 
     // ---- DMA descriptors (tile-invariant parts).  K sub-tile kk: this wave fills rows 16w .. 16w+15, lane l = (row l>>2, physical slot l&3).
-    const int krow = wave * 16 + (lane >> 2);
+    // K piece p = wave + NW * i (i < KPW): sub-tile p / 4, rows 16 * (p % 4) ..; with 4 waves a wave fills the same 16 rows of
+    // every sub-tile, with 8 waves (d <= 64) each wave fills one piece.
+    const int krow = ((wave + 0) & 3) * 16 + (lane >> 2);                 // NW is 4 or 8: p % 4 == wave % 4 for every i
     const int kcol = (((lane & 3) ^ ((krow >> 1) & 3)) << 3);             // logical column (halfs) inside the sub-tile
     // tile row krow = 32c + 16h + 4g + r holds key 32c + 8g + 4h + r (see the header): PV fragments become 16-byte reads
     const int kkey = (krow & 32) | (((krow >> 2) & 3) << 3) | (((krow >> 4) & 1) << 2) | (krow & 3);
@@ -138,42 +143,52 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     int vrow[VPW], vkey[VPW];
 #pragma unroll
     for (int i = 0; i < VPW; ++i) {
-        const int j = wave + 4 * i;
+        const int j = wave + NW * i;
         vrow[i] = j * 8 + (lane >> 3);
         vkey[i] = (((lane & 7) ^ ((vrow[i] >> 1) & 7)) << 3);             // first key (within the tile) of the logical slot
     }
     h16 *dummy = smem + NS * STAGE_H;
-    // per-lane source pointers of tile 0; a tile step is a constant stride (no 64-bit multiplies in the loop)
-    const h16 *kptr = kp + (long long)kkey * a.ldk + kcol;               // + kk * 32
-    const long long kstep = 64ll * a.ldk;
-    const h16 *vptr[VPW];
+    // Per-lane source pointers of tile 0 and their per-tile strides.  The loop is bound by instruction issue, so the DMA side
+    // is kept to "pointer += stride; load" per piece: lanes that only ever fetch padding (d = 40: columns 40..63 of the second
+    // K sub-tile) point at the zero page with stride 0 instead of being exec-masked (no divergent branches around the DMAs),
+    // and the key < Tk test exists only in the code path of the last tile.
+    const h16 *kptr[KPW];
+    long long kadv[KPW];
 #pragma unroll
-    for (int i = 0; i < VPW; ++i) vptr[i] = vp + (long long)vrow[i] * a.ldvt + vkey[i];
+    for (int i = 0; i < KPW; ++i) {
+        const int pc = wave + NW * i, kk = pc >> 2;
+        const bool real = pc < NKI && kk * 32 + kcol < D;
+        kptr[i] = real ? kp + (long long)kkey * a.ldk + kk * 32 + kcol : a.zero;
+        kadv[i] = real ? 64ll * a.ldk : 0ll;
+    }
+    const h16 *vptr[VPW];
+    long long vadv[VPW];
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const bool real = (wave + NW * i) < NVI && vrow[i] < D;
+        vptr[i] = real ? vp + (long long)vrow[i] * a.ldvt + vkey[i] : a.zero;
+        vadv[i] = real ? 64ll : 0ll;
+    }
 
     int is_slot = 0, is_key0 = 0;
-    auto issue = [&]() {                                                  // LPS DMA wave-instructions, always
+    auto issue = [&](auto last_tag) {                                     // LPS DMA wave-instructions, always
+        constexpr bool LAST = decltype(last_tag)::value;                  // only the last tile can reach beyond Tk
         h16 *st = smem + is_slot * STAGE_H;
-        const bool kin = (is_key0 + kkey) < a.Tk;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            if (kk * 32 + kcol < D) {                                     // padding columns stay zero: lane masked off
-                const h16 *src = kin ? kptr + kk * 32 : a.zero;
-                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + kk * 2048 + wave * 512), 16, 0, 0);
-            }
+        for (int i = 0; i < KPW; ++i) {
+            const int pc = wave + NW * i;                                 // wave-uniform piece index
+            const h16 *src = (LAST && is_key0 + kkey >= a.Tk) ? a.zero : kptr[i];
+            h16 *dst = pc < NKI ? st + (pc >> 2) * 2048 + (pc & 3) * 512 : dummy;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
+            kptr[i] += kadv[i];
         }
-        kptr += kstep;
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
-            const int j = wave + 4 * i;                                   // wave-uniform
-            if (j < NVI) {
-                if (vrow[i] < D) {
-                    const h16 *src = (is_key0 + vkey[i] < a.Tk) ? vptr[i] : a.zero;
-                    __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(st + KH + j * 512), 16, 0, 0);
-                }
-                vptr[i] += 64;
-            } else {
-                __builtin_amdgcn_global_load_lds(L2D_GPTR(a.zero), L2D_LPTR(dummy), 16, 0, 0);   // keeps vmcnt bookkeeping uniform
-            }
+            const int j = wave + NW * i;                                  // wave-uniform
+            const h16 *src = (LAST && is_key0 + vkey[i] >= a.Tk) ? a.zero : vptr[i];
+            h16 *dst = j < NVI ? st + KH + j * 512 : dummy;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
+            vptr[i] += vadv[i];
         }
         is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
         is_key0 += 64;
@@ -256,7 +271,8 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         // sacc already is  s*c - mref.  Raise the reference (rarely after the first tile): everything still at the old
         // reference -- O, l and THIS tile's not yet exponentiated scores -- is moved to the new one exactly once.  A subtile
         // whose maximum did not grow gets delta = 0, alpha = 1: the same code path, exact.
-        if (FIRST || __any((QS == 2 ? fmaxf(mx[0], mx[QS - 1]) : mx[0]) > 8.0f)) {
+        if (FIRST || __builtin_expect(__any((QS == 2 ? fmaxf(mx[0], mx[QS - 1]) : mx[0]) > 8.0f), 0)) {
+            asm volatile("" ::: "memory");   // volatile: the rarely needed rescale arithmetic must not be speculated into the hot path
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs) {
                 const float delta = FIRST ? mx[qs] : fmaxf(mx[qs], 0.f);
@@ -319,32 +335,42 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         const int first = a.Tk & 63, last = ((a.Tk + 7) & ~7) & 63;      // key columns inside the last tile
         if ((a.Tk & 7) == 0) return;
         h16 *vs = smem + ((nt - 1) % NS) * STAGE_H + KH;
-        for (int r = tid; r < D; r += 256) {
+        for (int r = tid; r < D; r += NT) {
             const int sw = (r >> 1) & 7;
             for (int c = first; c < (last == 0 ? 64 : last); ++c) vs[r * 64 + ((((c >> 3) ^ sw)) << 3) + (c & 7)] = (h16)0.0f;
         }
         __syncthreads();
     };
 
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     __syncthreads();                                                      // static LDS content in place before any DMA lands
     // prologue: NS-1 tiles in flight
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nt) issue();
-    using T_ = std::true_type;
-    using F_ = std::false_type;
+        if (s < nt) {
+            if (s == nt - 1) issue(T_{});
+            else issue(F_{});
+        }
     int kt = 0;
     if (NS - 1 < nt) {                     // tile 0 with a refill behind it
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();
-        issue();
+        if (NS - 1 == nt - 1) issue(T_{});
+        else issue(F_{});
         compute(0, T_{}, F_{});
         kt = 1;
     }
-    for (; kt + (NS - 1) < nt; ++kt) {
+    for (; kt + NS < nt; ++kt) {           // refills of tiles < nt - 1: no bounds test anywhere in this loop
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; everyone finished tile kt-1
-        issue();                           // refill the ring slot tile kt-1 occupied
+        issue(F_{});                       // refill the ring slot tile kt-1 occupied
+        compute(kt, F_{}, F_{});
+    }
+    for (; kt + (NS - 1) < nt; ++kt) {     // the one refill that fetches the last tile
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(T_{});
         compute(kt, F_{}, F_{});
     }
     // drain: no more refills.  (Waiting for everything costs nothing here: at most NS-1 short tiles remain.)
@@ -388,42 +414,58 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     }
 }
 
-// 4 waves x (16 * QS) queries; 2 blocks per CU (d <= 80: ring <= 68 KB) -> two waves per SIMD from DIFFERENT blocks, whose
-// MFMA and softmax phases drift apart and overlap.  The occupancy hint also keeps the accumulators out of the AGPR file.
-template <int D, int QS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void flash_ring_kernel(FARArgs a) {
-    flash_ring_body<D, QS>(a);
+// NW waves x (16 * QS) queries per block.  The SIMD issues at most one VALU and one MFMA per 4 cycles, from DIFFERENT
+// waves: with two waves per SIMD the in-order streams (28 MFMA + ~140 VALU + waits per wave and tile at d = 40) leave both
+// pipes idle half of the time (PMC: 43 % issuing, 29 % waiting on counters / barriers, 28 % on dependencies).  More, thinner
+// waves per SIMD fill those slots: QS = 1 halves the registers (<= 128: four waves per SIMD), and either 8 waves share a
+// block's K / V tiles (same L2 -> LDS traffic per query as 4 x 32) or the ring is made shallow so that 4 blocks fit a CU.
+// The occupancy hint also keeps the accumulators out of the AGPR file.
+template <int D, int QS, int NW, int NSF>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(QS == 1 && D <= 80 ? 3 : 2))) void flash_ring_kernel(FARArgs a) {
+    flash_ring_body<D, QS, NW, NSF>(a);
 }
 
-template <int D, int QS>
+template <int D, int QS, int NW, int NSF>
 static int launch_far_q(const FARArgs &a, hipStream_t s) {
-    using Cf = FARCfg<D>;
+    using Cf = FARCfg<D, NW, NSF>;
     static bool attr_done = false;
     if (Cf::LDS > 65536 && !attr_done) {
-        if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS, NW, NSF>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
     }
-    dim3 grid(((a.Tq + 64 * QS - 1) / (64 * QS)) * a.H * a.B);      // 1-D: decoded XCD-aware in the kernel
-    hipLaunchKernelGGL((flash_ring_kernel<D, QS>), grid, dim3(256), Cf::LDS, s, a);
+    dim3 grid(((a.Tq + 16 * NW * QS - 1) / (16 * NW * QS)) * a.H * a.B);      // 1-D: decoded XCD-aware in the kernel
+    hipLaunchKernelGGL((flash_ring_kernel<D, QS, NW, NSF>), grid, dim3(64 * NW), Cf::LDS, s, a);
     return L2D_OK;
 }
 
+// geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows; 4 = 8 waves x 16 rows (d <= 40); 5 = 4 waves x 16 rows with a
+// 2-deep ring (4-5 blocks per CU)
 template <int D>
-static int launch_far(const FARArgs &a, int qs, hipStream_t s) {
-    if (qs == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
+static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
+    if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
         const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
-        qs = (big >= 384) ? 2 : 1;
+        geo = (big >= 384) ? 2 : 3;
+        static int forced = -1;            // tuning knob: L2D_FLASH_GEO overrides the auto choice where the geometry exists
+        if (forced < 0) {
+            const char *e = getenv("L2D_FLASH_GEO");
+            forced = e ? atoi(e) : 0;
+        }
+        if (forced >= 2 && forced <= 5 && big >= 384) geo = forced;
     }
     if constexpr (D <= 80) {          // d = 160 with 32 query rows per wave does not fit the register file
-        if (qs == 2) return launch_far_q<D, 2>(a, s);
+        if (geo == 2) return launch_far_q<D, 2, 4, 0>(a, s);
     }
-    return launch_far_q<D, 1>(a, s);
+    if constexpr (D <= 40) {
+        if (geo == 4) return launch_far_q<D, 1, 8, 0>(a, s);
+        if (geo == 5) return launch_far_q<D, 1, 4, 2>(a, s);
+    }
+    return launch_far_q<D, 1, 4, 0>(a, s);
 }
 
 // called from l2d_launch_flash_attn (flash_attn.hip) after argument validation
-int l2d_launch_flash_ring(const l2d_op *op, int qs, hipStream_t s) {
+int l2d_launch_flash_ring(const l2d_op *op, int geo, hipStream_t s) {
     FARArgs a;
     a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
     a.zero = (const h16 *)op->p[4];
@@ -437,12 +479,12 @@ int l2d_launch_flash_ring(const l2d_op *op, int qs, hipStream_t s) {
     a.ldq = op->i[5]; a.ldk = op->i[6]; a.ldvt = op->i[7]; a.ldo = op->i[8];
     a.sq = op->l[0]; a.sk = op->l[1]; a.svt = op->l[2]; a.so = op->l[3];
     switch (a.d) {
-        case 8: return launch_far<8>(a, qs, s);
-        case 16: return launch_far<16>(a, qs, s);
-        case 32: return launch_far<32>(a, qs, s);
-        case 40: return launch_far<40>(a, qs, s);
-        case 80: return launch_far<80>(a, qs, s);
-        case 160: return launch_far<160>(a, qs, s);
+        case 8: return launch_far<8>(a, geo, s);
+        case 16: return launch_far<16>(a, geo, s);
+        case 32: return launch_far<32>(a, geo, s);
+        case 40: return launch_far<40>(a, geo, s);
+        case 80: return launch_far<80>(a, geo, s);
+        case 160: return launch_far<160>(a, geo, s);
     }
     return L2D_EINVAL;
 }

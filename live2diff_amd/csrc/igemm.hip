@@ -50,8 +50,33 @@ struct IGemmArgs {
     float *ws;         // split-K workspace [S][M][NoutP] fp32
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
     int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order, epl;
+    // GroupNorm statistics of the output for up to two consumer GroupNorms (0 = none): fixed-point int64 accumulators
+    // [sample][G][2]; T tokens per sample; (channels per group, channel offset in the consumer's concatenated axis) each
+    unsigned long long *gn1, *gn2;
+    int gnT, gnG, cpg1, choff1, cpg2, choff2;
     long long sx1, sw, so, sres;
 };
+
+// sum x in units of 2^-20, sum x^2 in units of 2^-12: integer adds commute, so the accumulated statistics do not depend on
+// the order in which blocks arrive (bit-repeatable frames), and |x| <= 65504 cannot overflow int64 at any size used here
+#define L2D_GN_S1_SCALE 1048576.0f
+#define L2D_GN_S2_SCALE 4096.0f
+
+// chs: per-channel (sum, sum of squares) of this block's tile, channels [c_lo, c_lo + nch) of the producing tensor, all of
+// sample `b`.  One thread per consumer group that overlaps the tile adds its channels and issues two integer atomics.
+__device__ __forceinline__ void igemm_gn_flush(unsigned long long *acc, int G, int cpg, int choff, int b, const float *chs1,
+                                               const float *chs2, int c_lo, int nch, int tid) {
+    if (!acc || nch <= 0) return;
+    const int first = choff + c_lo, last = first + nch - 1;
+    const int g0 = first / cpg, g = g0 + tid;
+    if (g > last / cpg || g >= G) return;
+    const int lo = max(g * cpg, first) - first, hi = min((g + 1) * cpg, last + 1) - first;
+    float s = 0.f, q = 0.f;
+    for (int c = lo; c < hi; ++c) { s += chs1[c]; q += chs2[c]; }
+    unsigned long long *dst = acc + ((long long)b * G + g) * 2;
+    atomicAdd(dst, (unsigned long long)__float2ll_rn(s * L2D_GN_S1_SCALE));
+    atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(q * L2D_GN_S2_SCALE));
+}
 
 // fused epilogue for 4 consecutive output channels n..n+3 of token m
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v) {
@@ -459,6 +484,13 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_ke
             }
         }
         __syncthreads();
+        const bool gn = a.gn1 != nullptr;
+        // this thread's 8 channels over its rows, as 4 channel PAIRS: every group size here is even (C is a multiple of 64,
+        // G = 32), so a pair never straddles two groups and v_dot2_f32_f16 does two channels per instruction
+        float gs[4], gq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+        const h16x2 ones2 = {(h16)1.0f, (h16)1.0f};
 #pragma unroll
         for (int it = 0; it < EPI_IT; ++it) {
             const int c = it * 256 + tid;
@@ -470,6 +502,37 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_ke
             if (resp) v = v + (RES_EARLY ? resv[RES_EARLY ? it : 0] : rlate[RES_EARLY ? 0 : it]);
             if (a.epi == 4) v = __builtin_elementwise_max(v, l2d_zero8());          // relu(conv + skip), TAESD blocks
             l2d_st8(outp + (long long)m * a.ldo + n, v);
+            if (gn) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h16x2 pr = {v[2 * e], v[2 * e + 1]};
+                    gs[e] = __builtin_amdgcn_fdot2(pr, ones2, gs[e], false);
+                    gq[e] = __builtin_amdgcn_fdot2(pr, pr, gq[e], false);
+                }
+            }
+        }
+        if (gn) {
+            // GroupNorm statistics of what was just stored (the fp16 values the consumer will read): thread -> channel
+            // -> group inside the block, then two integer atomics per (consumer, overlapped group).  The plan builder only
+            // asks for this when a tile lies inside one sample.
+            __syncthreads();                                            // every thread is done reading the staged tile
+            float *red = reinterpret_cast<float *>(smem);               // [256][8]: 4 pair sums | 4 pair sums of squares
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = gs[e]; red[tid * 8 + 4 + e] = gq[e]; }
+            __syncthreads();
+            float *chs1 = red + 256 * 8, *chs2 = chs1 + TN / 2;         // per channel pair
+            const int tno = (a.epi == 1) ? TN / 2 : TN;
+            if (tid < tno / 2) {
+                const int cc = tid >> 2, e = tid & 3;
+                float s = 0.f, q = 0.f;
+                for (int r = 0; r < (256 >> cshift); ++r) { s += red[((r << cshift) | cc) * 8 + e]; q += red[((r << cshift) | cc) * 8 + 4 + e]; }
+                chs1[tid] = s; chs2[tid] = q;
+            }
+            __syncthreads();
+            // group sums in units of channel pairs (cpg, offsets and tile origin are all even)
+            const int nch = min(tno, NoutO - n0o), bsmp = m0 / a.gnT;
+            igemm_gn_flush(a.gn1, a.gnG, a.cpg1 >> 1, a.choff1 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
+            igemm_gn_flush(a.gn2, a.gnG, a.cpg2 >> 1, a.choff2 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
         }
         return;
     }
@@ -512,20 +575,53 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_ke
     }
 }
 
-// sums the S fp32 partial tiles of a split-K launch and applies the fused epilogue
+// sums the S fp32 partial tiles of a split-K launch and applies the fused epilogue.  A block owns a 64-token x 64-channel
+// tile (thread = 4 channels x 4 token rows), which also lets it accumulate the GroupNorm statistics of its output.
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S) {
     const int NoutP = (a.Nout + 3) & ~3;
-    const int n4 = NoutP >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)a.M * n4) return;
-    const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
+    const int tiles_n = (NoutP + 63) / 64;
+    const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+    const int tid = threadIdx.x, cq = tid & 15, r0 = tid >> 4;
+    const int n = tn * 64 + cq * 4;
     const long long z = blockIdx.z;
-    const float *wsp = a.ws + (long long)z * S * a.M * NoutP + (long long)m * NoutP + n;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(wsp);
     const long long slab = (long long)a.M * NoutP;
+    const bool gn = a.gn1 != nullptr;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < NoutP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = tm * 64 + r0 + 16 * k;
+            if (m >= a.M) break;
+            const float *wsp = a.ws + (long long)z * S * slab + (long long)m * NoutP + n;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(wsp);
 #pragma unroll 8
-    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + s * slab);   // (unrolled: loads in flight together; same order)
-    igemm_epilogue(a, a.out + z * a.so, a.res ? a.res + z * a.sres : nullptr, m, n, v);
+            for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(wsp + s * slab);   // (unrolled: loads in flight together; same order)
+            h16 *outp = a.out + z * a.so;
+            igemm_epilogue(a, outp, a.res ? a.res + z * a.sres : nullptr, m, n, v);
+            if (gn) {                       // what was stored, as the consumer will read it (same thread, same addresses)
+                const h16x4 o = *reinterpret_cast<const h16x4 *>(outp + (long long)m * a.ldo + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float f = (float)o[e]; gs[e] += f; gq[e] = fmaf(f, f, gq[e]); }
+            }
+        }
+    }
+    if (gn) {
+        __shared__ float red[256][8];
+        __shared__ float chs[2][64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[tid][e] = gs[e]; red[tid][4 + e] = gq[e]; }
+        __syncthreads();
+        if (tid < 64) {
+            const int c4 = tid >> 2, e = tid & 3;
+            float s = 0.f, q = 0.f;
+            for (int r = 0; r < 16; ++r) { s += red[r * 16 + c4][e]; q += red[r * 16 + c4][4 + e]; }
+            chs[0][tid] = s; chs[1][tid] = q;
+        }
+        __syncthreads();
+        const int nch = min(64, a.Nout - tn * 64), bsmp = (tm * 64) / a.gnT;
+        igemm_gn_flush(a.gn1, a.gnG, a.cpg1, a.choff1, bsmp, chs[0], chs[1], tn * 64, nch, tid);
+        igemm_gn_flush(a.gn2, a.gnG, a.cpg2, a.choff2, bsmp, chs[0], chs[1], tn * 64, nch, tid);
+    }
 }
 
 template <int TN, int TM, int MODE, int BK, int NS>
@@ -587,6 +683,9 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.epl = ((op->i[22] >> 5) & 1) ? 0 : 1;   // + 32: direct (register -> global, 8-byte pieces) epilogue instead of the LDS-staged one
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
+    a.gn1 = (unsigned long long *)op->p[9]; a.gn2 = (unsigned long long *)op->p[10];
+    a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
+    if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     a.Kp = a.taps * a.CinP;
     if (!a.x1 || !a.w || !a.out || !a.zero || (a.taps != 1 && a.taps != 9) || a.CinP <= 0 || a.CinP % 64 != 0 ||
         a.M <= 0 || a.Nout <= 0 || (a.C1 % 8) || (a.C2 % 8) || (a.C2 > 0 && !a.x2) || a.C1 + a.C2 > a.CinP ||
@@ -598,6 +697,17 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
         return L2D_EINVAL;
+    }
+    if (a.gn1) {
+        const int tm = (a.splitk > 1 || tile == 2) ? 64 : 128;     // (tile 0 = auto is resolved below: require the larger one)
+        const bool vec_ok = a.epl && (a.Nout % 8) == 0 && (a.ldo % 8) == 0 && !(a.res && (a.ldr % 8)) && a.epi != 1;
+        if (a.gnT <= 0 || a.gnG <= 0 || a.gnG > 32 || a.cpg1 <= 0 || (a.gn2 && a.cpg2 <= 0) || batch != 1 ||
+            ((a.cpg1 | a.choff1) & 1) || (a.gn2 && ((a.cpg2 | a.choff2) & 1)) ||
+            (a.gnT % tm) != 0 || (a.splitk == 1 && !vec_ok) || (a.M % a.gnT) != 0) {
+            l2d_set_error("igemm(tag %d): GroupNorm statistics need T %% tile == 0 (T=%d tile=%d), the LDS-staged epilogue or "
+                          "split-K, batch 1 and G <= 32", op->tag, a.gnT, tm);
+            return L2D_EINVAL;
+        }
     }
     if (a.taps == 9 && (a.M != a.B * a.Hout * a.Wout)) {
         l2d_set_error("igemm(tag %d): M != B*Hout*Wout", op->tag);
@@ -616,7 +726,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     int rc = l2d_check_launch("igemm", op->tag);
     if (rc != L2D_OK || a.splitk == 1) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
-    long long total = (long long)a.M * (NoutP / 4);
-    hipLaunchKernelGGL(igemm_splitk_epilogue, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, s, a, a.splitk);
+    const unsigned tiles = (unsigned)(((NoutP + 63) / 64) * ((a.M + 63) / 64));
+    hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(tiles, 1, batch), dim3(256), 0, s, a, a.splitk);
     return l2d_check_launch("igemm_splitk_epilogue", op->tag);
 }

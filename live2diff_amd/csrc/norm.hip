@@ -17,6 +17,7 @@ struct GNArgs {
     h16 *out;
     int B, T, C1, C2, ld1, ld2, G, nchunk, silu;
     float eps;
+    const long long *acc;     // nchunk == 0: fixed-point statistics [B][G][2] accumulated by the producing GEMMs (igemm.hip)
 };
 
 // thread -> (pixel row within the pass, 8-channel vector column); returns false if idle
@@ -95,7 +96,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
     const int b = blockIdx.y;
-    {   // deterministic reduction of the per-chunk partials: 4 slices x G groups in parallel, fixed order
+    if (a.nchunk == 0) {   // statistics arrive as integers in units of 2^-20 (sum) and 2^-12 (sum of squares)
+        const int g = tid & 63, part = tid >> 6;
+        float s = 0.f, q = 0.f;
+        if (g < a.G && part == 0) {
+            const long long *src = a.acc + ((long long)b * a.G + g) * 2;
+            s = (float)((double)src[0] * (1.0 / 1048576.0));
+            q = (float)((double)src[1] * (1.0 / 4096.0));
+        }
+        s_part[part][g][0] = s; s_part[part][g][1] = q;
+    } else {   // deterministic reduction of the per-chunk partials: 4 slices x G groups in parallel, fixed order
         const int g = tid & 63, part = tid >> 6;
         float s = 0.f, q = 0.f;
         if (g < a.G) {
@@ -162,9 +172,11 @@ static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
     a.gamma = (const h16 *)op->p[3]; a.beta = (const h16 *)op->p[4]; a.out = (h16 *)op->p[5];
     a.B = op->i[0]; a.T = op->i[1]; a.C1 = op->i[2]; a.C2 = op->i[3]; a.ld1 = op->i[4]; a.ld2 = op->i[5];
     a.G = op->i[6]; a.nchunk = op->i[7]; a.silu = op->i[8]; a.eps = op->f[0];
+    a.acc = (const long long *)op->p[6];
     int C = a.C1 + a.C2;
+    if (apply && a.nchunk == 0 && a.acc) a.partial = (float *)a.acc;      // accumulator mode: no partial buffer
     if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 32 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
-        (a.C2 > 0 && !a.x2) || a.nchunk <= 0 || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
+        (a.C2 > 0 && !a.x2) || a.nchunk < 0 || (a.nchunk == 0 && !(apply && a.acc)) || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
         (apply && (!a.gamma || !a.beta || !a.out))) {
         l2d_set_error("groupnorm(tag %d): invalid arguments (B=%d T=%d C1=%d C2=%d G=%d nchunk=%d)", op->tag, a.B, a.T,
                       a.C1, a.C2, a.G, a.nchunk);

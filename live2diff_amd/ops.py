@@ -78,6 +78,29 @@ def zero_page(device) -> torch.Tensor:
     return _ZERO_PAGES[key]
 
 
+def igemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """Ask an igemm op to accumulate the GroupNorm statistics of its output for one consumer GroupNorm (up to two per op):
+    `acc_ptr` -> int64 [samples][G][2], cpg / choff = channels per group and channel offset of this tensor in the consumer's
+    (concatenated) channel axis.  Returns False when both slots are taken or the launch cannot do it (include/l2d.h)."""
+    assert op.kind == _lib.OP_IGEMM
+    splitk, tile = max(1, op.i[21]), op.i[22] & 15
+    tm = 64 if (splitk > 1 or tile == 2) else 128
+    Nout, ldo, ldr, epi, batch = op.i[14], op.i[15], op.i[16], op.i[19], max(1, op.i[20])
+    direct = (op.i[22] >> 5) & 1
+    vec_ok = (not direct) and Nout % 8 == 0 and ldo % 8 == 0 and not (op.p[5] and ldr % 8) and epi != 1
+    if T % tm or batch != 1 or (splitk == 1 and not vec_ok) or op.i[13] % T or G > 32:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
+
+
 def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, taps: int = 1):
     """(tile, splitk, variant) for an implicit GEMM, from the on-GPU sweep (tools/igemm_sweep.py, profiles/r1b_igemm_sweep.txt).
     tile 1 = 128x128, 2 = 64x64; variant = pipeline shape (igemm.hip launch_p).  These kernels are occupancy /
@@ -174,10 +197,15 @@ def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):
     return op, (x1, x2, partial)
 
 
-def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0):
+def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0, acc_ptr=None):
+    """nchunk = 0 + acc_ptr: the statistics come from the fixed-point accumulators [B][G][2] int64 that the producing igemm
+    launches filled (igemm `gn_target`), `partial` is unused (None)."""
     op = L2dOp()
     op.kind = _lib.OP_GN_APPLY
     op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), _ptr(x2), _ptr(partial)
+    if acc_ptr is not None:
+        assert nchunk == 0
+        op.p[6] = int(acc_ptr)
     op.p[3], op.p[4], op.p[5] = _ptr(_h(gamma)), _ptr(_h(beta)), _ptr(_h(out))
     for j, v in enumerate([B, T, C1, C2, ld1, ld2, G, nchunk, 1 if silu else 0]):
         op.i[j] = int(v)

@@ -85,11 +85,11 @@ class _Arena:
 
 
 class _Act:
-    """channels-last activation: buf holds [B*H*W, C] halfs (ld == C)."""
-    __slots__ = ("buf", "C", "H", "W")
+    """channels-last activation: buf holds [B*H*W, C] halfs (ld == C); `producer` = the igemm op that wrote it (if any)."""
+    __slots__ = ("buf", "C", "H", "W", "producer")
 
-    def __init__(self, buf, C, H, W):
-        self.buf, self.C, self.H, self.W = buf, C, H, W
+    def __init__(self, buf, C, H, W, producer=None):
+        self.buf, self.C, self.H, self.W, self.producer = buf, C, H, W, producer
 
 
 class HipStreamingUNet:
@@ -369,11 +369,31 @@ class HipStreamingUNet:
         def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
             T = x.H * x.W
             C2 = x2.C if x2 is not None else 0
+            out = new_act(x.C + C2, x.H, x.W)
+            # Statistics from the producers: the igemm launches that wrote x (and x2) accumulate sum / sum of squares per
+            # (sample, group of THIS GroupNorm) in their epilogues as fixed-point integer atomics -- no gn_stats launch, no
+            # second pass over the tensor.  Falls back to the stats kernel when a producer cannot (tile straddles samples,
+            # both of its target slots taken, direct epilogue forced).
+            cpg = (x.C + C2) // G
+            ins = [(x, 0)] + ([(x2, x.C)] if x2 is not None else [])
+            if st.gn_fuse and all(a_.producer is not None for a_, _ in ins) and st.gn_layers < st.gn_acc.shape[0]:
+                acc_ptr = st.gn_acc.data_ptr() + st.gn_layers * B * G * 2 * 8
+                saved = [(a_.producer, [a_.producer.p[9], a_.producer.p[10]], list(a_.producer.i[24:30])) for a_, _ in ins]
+                if all(ops.igemm_gn_target(a_.producer, acc_ptr, T=T, G=G, cpg=cpg, choff=off) for a_, off in ins):
+                    st.gn_layers += 1
+                    add(ops.gn_apply(x.buf, None, W[name + ".g"], W[name + ".beta"], out.buf, eps=eps, silu=silu, B=B, T=T, C1=x.C,
+                                     ld1=x.C, G=G, nchunk=0, x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2,
+                                     acc_ptr=acc_ptr))
+                    return out
+                for op_, ps, is_ in saved:                   # undo a half-attached layer
+                    op_.p[9], op_.p[10] = ps
+                    for j, v in enumerate(is_):
+                        op_.i[24 + j] = v
             nchunk = max(1, min(int(os.environ.get("L2D_GN_NCHUNK", "64")), T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
-            out = new_act(x.C + C2, x.H, x.W)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
                       ld2=C2)
+            st.gn_stats_launches += 1
             add(ops.gn_stats(x.buf, partial, **kw))
             add(ops.gn_apply(x.buf, partial, W[name + ".g"], W[name + ".beta"], out.buf, eps=eps, silu=silu, **kw))
             ar.release(partial)
@@ -400,21 +420,22 @@ class HipStreamingUNet:
                             taps=9, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, stride=stride, ups=ups, epi=epi, **kw)
             if rowbias is not None:
                 op_.p[4] = st.temb_all.data_ptr() + 4 * rowbias
+            out.producer = op_
             return out
 
         def linear_raw(xbuf, M, K, ldx, wt, outbuf, ldo, bias=None, res=None, ldr=0, epi=0, x2=None, C2=0, ldx2=0,
                        **kw):
             nout = wt.shape[0]
-            gemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
-                          res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw)
+            return gemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
+                        res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw)
 
         def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None) -> _Act:
             wt = W[wkey or (name + ".w")]
             out = new_act(wt.shape[0], x.H, x.W)
-            linear_raw(x.buf, B * x.H * x.W, x.C, x.C, wt, out.buf, wt.shape[0], bias=(W[name + ".b"] if bias else None),
-                       res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
-                       x2=(x2.buf if x2 is not None else None), C2=(x2.C if x2 is not None else 0),
-                       ldx2=(x2.C if x2 is not None else 0))
+            out.producer = linear_raw(x.buf, B * x.H * x.W, x.C, x.C, wt, out.buf, wt.shape[0], bias=(W[name + ".b"] if bias else None),
+                                      res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
+                                      x2=(x2.buf if x2 is not None else None), C2=(x2.C if x2 is not None else 0),
+                                      ldx2=(x2.C if x2 is not None else 0))
             return out
 
         def layernorm(x: _Act, name) -> _Act:
@@ -551,6 +572,12 @@ class HipStreamingUNet:
                       so=self.text_total * TEXT_PAD)
 
         cur[0] = pl
+        # ---- GroupNorm statistics accumulators (one [B][G][2] int64 block per fused GroupNorm), zeroed once per frame
+        st.gn_fuse = os.environ.get("L2D_GN_FUSE", "1") != "0" and os.environ.get("L2D_IGEMM_EPI", "1") != "0"
+        st.gn_layers, st.gn_stats_launches = 0, 0
+        st.gn_acc = torch.zeros(96, B, G, 2, dtype=torch.int64, device=dev)
+        st.gn_zero = torch.zeros_like(st.gn_acc)
+        zero_op = add(ops.copy(st.gn_zero, st.gn_acc, st.gn_acc.numel() * 8)) if st.gn_fuse else None
         # ---- input: NCHW latents -> channels-last (padded to 8 channels), conv_in + depth mapping network
         x_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
         d_in = _Act(ar.alloc(B * h * w * 8), 8, h, w)
@@ -606,6 +633,8 @@ class HipStreamingUNet:
         free(x)
         y = conv3(hn, "conv_out")
         add(ops.nhwc_to_nchw(y.buf, st.out_sample, B=B, C=cfg.out_channels, HW=h * w, ld=cfg.out_channels))
+        if zero_op is not None:
+            zero_op.l[0] = max(16, st.gn_layers * B * G * 2 * 8)          # only the blocks in use
         st.kv_ptrs = [c.data_ptr() for c in kv_cache]
         st.arena_bytes = ar.nbytes()
         st.n_ops = len(pl)
@@ -730,4 +759,4 @@ class HipStreamingUNet:
         kinds = {}
         for j in range(len(st.pl)):
             kinds[st.pl[j].kind] = kinds.get(st.pl[j].kind, 0) + 1
-        return dict(n_ops=len(st.pl), n_cond_ops=len(st.cond_pl), kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())
+        return dict(n_ops=len(st.pl), n_cond_ops=len(st.cond_pl), gn_fused=st.gn_layers, gn_stats_launches=st.gn_stats_launches, kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())

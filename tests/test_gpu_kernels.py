@@ -219,6 +219,65 @@ def test_groupnorm(L, C1, C2, T, silu):
     check(out, ref, what=f"groupnorm {C1}+{C2} T{T}")
 
 
+@pytest.mark.parametrize("B,T,K,C,tile,splitk,choff2,Ccat", [
+    (2, 4096, 320, 320, 1, 1, 0, 640),        # 128x128 tile, cpg 10 / 20: groups straddle the 128-channel tiles
+    (2, 1024, 640, 640, 2, 1, 640, 1280),     # 64x64 tile; second consumer sees this tensor as the upper half of a concat
+    (2, 256, 1280, 1280, 2, 1, 1280, 1920),   # concat 1280 + 640: cpg 60, a group straddles the two inputs
+    (2, 64, 2560, 1280, 2, 4, 0, 2560),       # split-K: statistics from the (tiled) split-K epilogue, T = 64
+    (8, 64, 320, 320, 2, 1, 0, 640),          # warm-up batch: 8 samples
+])
+def test_igemm_groupnorm_statistics_from_the_producer(L, B, T, K, C, tile, splitk, choff2, Ccat):
+    """The producer GEMM accumulates sum / sum of squares of its OUTPUT per (sample, group) for up to two consumer GroupNorms
+    as fixed-point integer atomics (include/l2d.h, igemm `gn` fields); gn_apply with nchunk = 0 normalises from them.
+    Checked against sums over the fp16 tensor the GEMM wrote, and against F.group_norm; repeated launches are bit-identical."""
+    from live2diff_amd import _lib
+    G, M = 32, B * T
+    x = rnd(M, K, seed=1)
+    w = rnd(C, K, seed=2, scale=K ** -0.5)
+    b = rnd(C, seed=3).float()
+    r = rnd(M, C, seed=4)
+    wp = L.pack_linear(w.to(DEV))
+    out = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ws = torch.empty(splitk * M * C, dtype=torch.float32, device=DEV) if splitk > 1 else None
+    acc = torch.zeros(2, B, G, 2, dtype=torch.int64, device=DEV)
+    cpg1, cpg2 = C // G, Ccat // G
+    accs = []
+    for rep in range(2):
+        acc.zero_()
+        op, keep = L.igemm(x.to(DEV), wp, out, M=M, Nout=C, C1=K, ldx1=K, CinP=wp.shape[1], ldo=C, bias=b.to(DEV), res=r.to(DEV), ldr=C,
+                           splitk=splitk, tile=tile, ws=ws, variant=1)
+        assert L.igemm_gn_target(op, acc[0].data_ptr(), T=T, G=G, cpg=cpg1, choff=0)
+        assert L.igemm_gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=choff2)
+        assert not L.igemm_gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=0)      # both slots taken
+        L.run((op, keep + (acc,)))
+        torch.cuda.synchronize()
+        accs.append(acc.clone())
+    assert torch.equal(accs[0], accs[1])                                   # integer accumulation: order-independent
+    o = out.float().cpu().view(B, T, C)
+    ref = x.float() @ w.float().t() + b + r.float()
+    check(out, ref, what="gemm output")
+    a0 = accs[0].cpu().double()
+    s1 = o.double().view(B, T, G, cpg1).sum((1, 3))
+    s2 = (o.double() ** 2).view(B, T, G, cpg1).sum((1, 3))
+    assert (a0[0, :, :, 0] / 2 ** 20 - s1).abs().max() <= 1e-3 * max(1.0, s1.abs().max().item())
+    assert (a0[0, :, :, 1] / 2 ** 12 - s2).abs().max() <= 1e-3 * s2.abs().max().item()
+    # consumer 2: this tensor occupies channels [choff2, choff2 + C) of a Ccat-channel concat
+    full = torch.zeros(B, T, Ccat, dtype=torch.float64)
+    full[:, :, choff2:choff2 + C] = o.double()
+    t1 = full.view(B, T, G, cpg2).sum((1, 3))
+    t2 = (full ** 2).view(B, T, G, cpg2).sum((1, 3))
+    assert (a0[1, :, :, 0] / 2 ** 20 - t1).abs().max() <= 1e-3 * max(1.0, t1.abs().max().item())
+    assert (a0[1, :, :, 1] / 2 ** 12 - t2).abs().max() <= 1e-3 * t2.abs().max().item()
+    # gn_apply from the accumulators == GroupNorm of the stored tensor
+    gm, bt = (1 + 0.1 * rnd(C, seed=5).float()).half(), (0.1 * rnd(C, seed=6).float()).half()
+    y = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    L.run(L.gn_apply(out, None, gm.to(DEV), bt.to(DEV), y, B=B, T=T, C1=C, ld1=C, G=G, nchunk=0, eps=1e-5, silu=True,
+                     acc_ptr=accs[0][0].contiguous().data_ptr() if False else acc[0].data_ptr()))
+    torch.cuda.synchronize()
+    gref = F.silu(F.group_norm(o.permute(0, 2, 1), G, gm.float(), bt.float(), 1e-5)).permute(0, 2, 1).reshape(M, C)
+    check(y, gref, what="gn_apply from producer statistics")
+
+
 @pytest.mark.parametrize("rows,C", [(7, 64), (8192, 320), (100, 1280), (33, 640)])
 def test_layernorm(L, rows, C):
     x = rnd(rows, C, seed=1) * 3 + 1
@@ -242,7 +301,7 @@ def test_flash_attn(L, d, Tq, Tk):
     ldvt = (Tk + 7) // 8 * 8
     vt = torch.full((B, C, ldvt), float("nan"), dtype=torch.float16)     # padding columns hold garbage
     vt[:, :, :Tk] = v.transpose(1, 2)
-    for variant in (1, 2, 3):       # register-staged kernel, LDS-DMA ring kernel with 32 / 16 query rows per wave
+    for variant in (1, 2, 3, 4, 5):       # register-staged kernel, LDS-DMA ring kernel with 32 / 16 query rows per wave
         out = torch.full((B, Tq, C), float("nan"), dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=Tq, Tk=Tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
                            sq=Tq * C, sk=Tk * C, svt=C * ldvt, so=Tq * C, variant=variant))
@@ -275,7 +334,7 @@ def test_flash_attn_long_sequences(L, d, T):
     q, k, v = (torch.randn(B, T, C, generator=g, device=DEV, dtype=torch.float16) for _ in range(3))
     ref = _sdpa_ref_blocks(q, k, v, H)
     vt = v.transpose(1, 2).contiguous()
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4, 5):
         out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q, k, vt, out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C, sq=T * C, sk=T * C, svt=C * T,
                            so=T * C, variant=variant))
@@ -301,7 +360,7 @@ def test_flash_attn_forced_rescale(L, d, scale, spike_tile):
     ref = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh
     ref = ref.transpose(1, 2).reshape(B, T, C)
     vt = v.transpose(1, 2).contiguous()
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4, 5):
         out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C,
                            sq=T * C, sk=T * C, svt=C * T, so=T * C, variant=variant))

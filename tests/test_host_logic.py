@@ -94,8 +94,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib.l2d_abi_version() == 1
-    assert ctypes.sizeof(_lib.L2dOp) == 232
+    assert _lib.lib.l2d_abi_version() == 2
+    assert ctypes.sizeof(_lib.L2dOp) == 280          # ABI v2: 12 pointers + 32 ints + 4 int64 + 4 floats (+ kind, tag)
     # error path without a device: refused loudly, no fallback
     ops = (_lib.L2dOp * 1)()
     ops[0].kind = 99
@@ -242,6 +242,8 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     kv = unet.prepare_cache(2)
     st = unet._plan("stream", kv)
     tot = {}
+    s_ = unet.plan_summary()
+    assert s_["gn_fused"] == 81 and s_["gn_stats_launches"] == 0      # every GroupNorm's statistics come from its producers
     assert len(st.cond_pl) == 6        # timestep sinusoid + 3 skinny GEMMs + text K / V^T: run when the conditioning changes
     for op in [st.cond_pl[j] for j in range(len(st.cond_pl))] + [st.pl[j] for j in range(len(st.pl))]:
         fl, by = bench.op_work(op, _lib)

@@ -28,7 +28,7 @@ def test_integration_md_snippets_run(dry_run, monkeypatch):
     import live2diff_amd.config as C
     from live2diff_amd.weights import unet_param_spec
     blocks = _blocks()
-    assert len(blocks) >= 2, "INTEGRATION.md lost its executable blocks"
+    assert len(blocks) >= 3, "INTEGRATION.md lost its executable blocks"
     ns = {}
     for b in blocks:
         exec(compile(b, "INTEGRATION.md", "exec"), ns)
@@ -60,3 +60,11 @@ def test_integration_md_snippets_run(dry_run, monkeypatch):
                       kv_cache=stream.kv_cache_list, pe_idx=torch.zeros(N, 16, dtype=torch.int64),
                       update_idx=torch.tensor([8, 9]), return_dict=True)
     assert out["sample"].shape == (N, 4, 1, h, w) and out["kv_cache"] is stream.kv_cache_list
+    # the sibling vae slot
+    from live2diff_amd.vae_hip import taesd_param_spec
+    vsd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in taesd_param_spec().items()}
+    stream.vae = SimpleNamespace(state_dict=lambda: vsd)
+    vae = ns["install_hip_vae"](stream, "cpu")
+    assert stream.vae is vae and vae.config.scaling_factor == 1.0 and vae.dtype == torch.float16
+    assert vae.encode(torch.zeros(1, 3, 128, 128, dtype=torch.float16)).latents.shape == (1, 4, 16, 16)
+    assert vae.decode(torch.zeros(1, 4, 16, 16, dtype=torch.float16), return_dict=False)[0].shape == (1, 3, 128, 128)
