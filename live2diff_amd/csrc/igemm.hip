@@ -124,7 +124,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
 
 // MODE 0: linear / 1x1 (taps = 1);  MODE 1: 3x3, single input, no upsample (fast gather);  MODE 2: 3x3 generic
 template <int TN, int TM, int MODE, int BK, int NS>
-__global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? 3 : 1) void igemm_kernel(IGemmArgs a) {
+__global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 1) void igemm_kernel(IGemmArgs a) {
     constexpr int NI = TN / 32;        // 16-row fragments per wave along channels
     constexpr int MI = TM / 32;        // 16-col fragments per wave along tokens
     constexpr int SPR = BK / 8;        // 16-byte slots per LDS row (4 or 8)
@@ -626,7 +626,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
 
 template <int TN, int TM, int MODE, int BK, int NS>
 static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
-    constexpr size_t LDS = (size_t)NS * (TN + TM) * BK * sizeof(h16);
+    constexpr size_t RING = (size_t)NS * (TN + TM) * BK * sizeof(h16);
+    constexpr size_t EPI = (size_t)TM * (TN + 8) * sizeof(h16);        // the LDS-staged epilogue's transposed tile
+    constexpr size_t LDS = RING > EPI ? RING : EPI;
     static bool attr_done = false;
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
         // (fails inside a stream capture: the plan's first run is always direct -- HipStreamingUNet._run; if it fails
@@ -642,7 +644,8 @@ static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
 }
 
 // pipeline variants (op.i[23]): 0 = BK32 x 4 stages, 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3,
-// 5 = BK64 x 2, 6 = BK128 x 2, 7 = BK128 x 3 (64x64 tile only), 8 = BK64 x 6 (64x64 only), 9 = BK64 x 4 (64x64 only)
+// 5 = BK64 x 2, 6 = BK128 x 2, 7 = BK128 x 3 (64x64 tile only), 8 = BK64 x 6 (64x64 only), 9 = BK64 x 4 (64x64 only),
+// 10 = BK32 x 2
 template <int TN, int TM, int MODE>
 static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
     switch (variant) {
@@ -656,6 +659,7 @@ static int launch_p(const IGemmArgs &a, int batch, int variant, hipStream_t s) {
         case 7: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 128, 3>(a, batch, s); return L2D_OK; } break;
         case 8: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 64, 6>(a, batch, s); return L2D_OK; } break;
         case 9: if constexpr (TN + TM <= 128) { launch_v<TN, TM, MODE, 64, 4>(a, batch, s); return L2D_OK; } break;
+        case 10: launch_v<TN, TM, MODE, 32, 2>(a, batch, s); return L2D_OK;   // shallow ring: 4 blocks of the 128x128 tile per CU
     }
     return L2D_EINVAL;
 }
@@ -693,7 +697,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
         a.epi < 0 || a.epi > 4 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
-        variant < 0 || variant > 9 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
+        variant < 0 || variant > 10 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
         return L2D_EINVAL;

@@ -114,7 +114,7 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, tap
     if force:
         t, S, v = (int(x) for x in force.split(","))
         S = max(1, min(S, Kp // 128))
-        ok = not (v in (6, 7) and (Kp // taps) % 128) and not (t == 1 and v in (7, 8, 9))
+        ok = not (v in (6, 7) and (Kp // taps) % 128) and not (t == 1 and v in (7, 8, 9)) and 0 <= v <= 10
         if ok:
             return t, S, v
     elif key in _TUNED:

@@ -222,7 +222,7 @@ def test_groupnorm(L, C1, C2, T, silu):
 @pytest.mark.parametrize("B,T,K,C,tile,splitk,choff2,Ccat", [
     (2, 4096, 320, 320, 1, 1, 0, 640),        # 128x128 tile, cpg 10 / 20: groups straddle the 128-channel tiles
     (2, 1024, 640, 640, 2, 1, 640, 1280),     # 64x64 tile; second consumer sees this tensor as the upper half of a concat
-    (2, 256, 1280, 1280, 2, 1, 1280, 1920),   # concat 1280 + 640: cpg 60, a group straddles the two inputs
+    (2, 256, 1280, 640, 2, 1, 1280, 1920),    # the 640-channel half of a 1280 + 640 concat: cpg 60, a group straddles the inputs
     (2, 64, 2560, 1280, 2, 4, 0, 2560),       # split-K: statistics from the (tiled) split-K epilogue, T = 64
     (8, 64, 320, 320, 2, 1, 0, 640),          # warm-up batch: 8 samples
 ])
