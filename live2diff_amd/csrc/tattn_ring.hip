@@ -27,6 +27,8 @@
 // outstanding stages and drain the pipeline, so the only ordinary loads are the next group's q row (issued L/8
 // stages before use) and the stores (never waited on).  The loop is instruction-issue bound on the SIMD that hosts
 // two of the block's five waves, hence v_dot2_f32_f16 / v_fma_mix_f32 and uniform control flow throughout.
+#include <stdlib.h>
+
 #include "tattn.h"
 
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
@@ -52,9 +54,12 @@ __device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
     }
 }
 
-template <int HG, int L>   // HG = threads per head (d / 8): 5, 10, 20
+// HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) = 100 KB of ring, one block per CU;
+// (2, 3) = 30 KB, TWO blocks per CU (76 KB each): ten waves instead of five on the CU's four SIMDs (the loop is issue bound on
+// the SIMD that hosts two of a block's five waves) and one block's DMA under the other's arithmetic.
+template <int HG, int L, int R, int NS>
 __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
-    constexpr int TP = 40, PB = 8, R = 4, NSTG = 2 * L / R, NS = 5, LPS = R;
+    constexpr int TP = 40, PB = 8, NSTG = 2 * L / R, LPS = R;
     constexpr int STAGE_H = R * PB * TP * 8;       // halfs per stage (20 KB)
     constexpr int LP = L + 4;
     // LDS: ring [NS][20 KB] | score rows [320][LP] f32 | bias of row n [L] f32 | k_pe rows [L][40][8] | v_pe rows
@@ -221,13 +226,13 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
     }
 }
 
-template <int L, int HG>
-static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
-    constexpr size_t LDS = (size_t)5 * 8 * 4 * 40 * 16 + (size_t)(320 * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
+template <int L, int HG, int R, int NS>
+static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
+    constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(320 * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static bool attr_done = false;
     if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel (not inside a stream capture: the
         // plan's first run is always direct; on failure the flag stays clear and the launch below reports the error)
-        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
@@ -235,9 +240,20 @@ static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_
     const int CH = a.C / 320;
     const int groups_per_unit = a.T / 8;
     const int total = a.N * CH * groups_per_unit;
-    const int gpb = (total + cus - 1) / cus;       // one LDS-filling block per CU, persistent over gpb groups
+    const int gpb = (total + slots - 1) / slots;   // LDS-filling blocks, persistent over gpb pixel groups
     const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L>), dim3(a.N * CH * bpu), dim3(320), LDS, s, a, zero, gpb, groups_per_unit);
+    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(320), LDS, s, a, zero, gpb, groups_per_unit);
+}
+
+template <int L, int HG>
+static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
+    static int geo = -1;                 // tuning knob L2D_TATTN_RING: 0 = (4 rows, 5 stages, 1 block / CU), 1 = (2, 3, 2 blocks / CU)
+    if (geo < 0) {
+        const char *e = getenv("L2D_TATTN_RING");
+        geo = e ? atoi(e) : 0;
+    }
+    if (geo == 1) launch_ring_g<L, HG, 2, 3>(a, zero, 2 * cus, s);
+    else launch_ring_g<L, HG, 4, 5>(a, zero, cus, s);
 }
 
 bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
