@@ -127,6 +127,16 @@ enum {
  *   p2 out float[2] = {min, max} ; l0 n ; i0 nb (blocks of the partial pass, <= 1024)
  * L2D_OP_DEPTH_NORM_RESIZE  ((d - min) / (max - min)) -> 3 channels -> * 2 - 1 -> bilinear resize, fp16 rounding after each
  *   reference tensor op:  p0 depth [B][Hd][Wd] half p1 {min, max} float[2] p2 out [B][3][H][W] half ; i0 B i1 Hd i2 Wd i3 H i4 W
+ *
+ * Depth detector (DPT-Hybrid; reference depth_utils.py:11-32): its GEMM-shaped work runs on L2D_OP_IGEMM
+ * (i30 = 1: TF-"SAME" low-side padding 0 for stride-2 3x3 convs; epi 5 = GELU) / L2D_OP_FLASH_ATTN (d = 64) /
+ * L2D_OP_GN_APPLY (i8 activation: 0 none, 1 SiLU, 2 ReLU, 3 ReLU(norm(x) + p7 residual)) / L2D_OP_LAYERNORM /
+ * L2D_OP_SKINNY_LINEAR (l0 = row stride of A, 0 = dense); the rest:
+ * L2D_OP_STEM7X7   weight-standardised 7x7 stride-2 SAME conv, 3 -> 64: p0 image [B,3,H,W] half (NCHW) p1 w [64][3][7][7] half
+ *   p2 out [B,ceil(H/2),ceil(W/2),64] half ; i0 B i1 H i2 W
+ * L2D_OP_RESAMPLE_NHWC  channels-last p0 in [B,H,W,C] -> p1 out ; i0 B i1 H i2 W i3 C (% 8) i4 mode: 0 = 3x3 stride-2 max pool
+ *   (SAME), 1 = stride-2 subsample, 2 = bilinear x2 upsample with align_corners=True
+ * L2D_OP_EW        s = p0 (+ p1); p2 = s (if given); p3 = relu(s) (if given) ; l0 n halfs (% 8)
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -148,6 +158,9 @@ enum {
     L2D_OP_RESIZE_BILINEAR = 17,
     L2D_OP_MINMAX = 18,
     L2D_OP_DEPTH_NORM_RESIZE = 19,
+    L2D_OP_STEM7X7 = 20,
+    L2D_OP_RESAMPLE_NHWC = 21,
+    L2D_OP_EW = 22,
 };
 
 typedef struct l2d_op {

@@ -48,6 +48,9 @@ static int run_one(const l2d_op *op, hipStream_t s) {
         case L2D_OP_RESIZE_BILINEAR: return l2d_launch_resize_bilinear(op, s);
         case L2D_OP_MINMAX: return l2d_launch_minmax(op, s);
         case L2D_OP_DEPTH_NORM_RESIZE: return l2d_launch_depth_norm_resize(op, s);
+        case L2D_OP_STEM7X7: return l2d_launch_stem7x7(op, s);
+        case L2D_OP_RESAMPLE_NHWC: return l2d_launch_resample_nhwc(op, s);
+        case L2D_OP_EW: return l2d_launch_ew(op, s);
         case L2D_OP_COPY: {
             if (!op->p[0] || !op->p[1] || op->l[0] <= 0) {
                 l2d_set_error("copy(tag %d): invalid arguments", op->tag);

@@ -39,6 +39,9 @@ int l2d_launch_randn(const l2d_op *op, hipStream_t s);
 int l2d_launch_resize_bilinear(const l2d_op *op, hipStream_t s);
 int l2d_launch_minmax(const l2d_op *op, hipStream_t s);
 int l2d_launch_depth_norm_resize(const l2d_op *op, hipStream_t s);
+int l2d_launch_stem7x7(const l2d_op *op, hipStream_t s);
+int l2d_launch_resample_nhwc(const l2d_op *op, hipStream_t s);
+int l2d_launch_ew(const l2d_op *op, hipStream_t s);
 
 #ifdef __HIPCC__
 // SiLU / GELU are evaluated per output element inside GEMM epilogues and the GroupNorm apply pass (tens of millions of

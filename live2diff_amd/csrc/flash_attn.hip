@@ -279,7 +279,7 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
     if (variant != 1 && ring_ok) {
         int rc = l2d_launch_flash_ring(op, variant >= 2 ? variant : 0, s);
         if (rc != L2D_OK) {
-            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,80,160)", op->tag, a.d);
+            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,64,80,160)", op->tag, a.d);
             return rc;
         }
         return l2d_check_launch("flash_attn_ring", op->tag);
@@ -289,10 +289,11 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
         case 16: launch_fa<16>(a, s); break;
         case 32: launch_fa<32>(a, s); break;
         case 40: launch_fa<40>(a, s); break;
+        case 64: launch_fa<64>(a, s); break;
         case 80: launch_fa<80>(a, s); break;
         case 160: launch_fa<160>(a, s); break;
         default:
-            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,80,160)", op->tag, a.d);
+            l2d_set_error("flash_attn(tag %d): unsupported head dim %d (built: 8,16,32,40,64,80,160)", op->tag, a.d);
             return L2D_EINVAL;
     }
     return l2d_check_launch("flash_attn", op->tag);

@@ -483,6 +483,7 @@ int l2d_launch_flash_ring(const l2d_op *op, int geo, hipStream_t s) {
         case 16: return launch_far<16>(a, geo, s);
         case 32: return launch_far<32>(a, geo, s);
         case 40: return launch_far<40>(a, geo, s);
+        case 64: return launch_far<64>(a, geo, s);
         case 80: return launch_far<80>(a, geo, s);
         case 160: return launch_far<160>(a, geo, s);
     }

@@ -141,3 +141,157 @@ int l2d_launch_depth_norm_resize(const l2d_op *op, hipStream_t s) {
                        (const float *)op->p[1], (h16 *)op->p[2], B, Hd, Wd, H, W);
     return l2d_check_launch("depth_norm_resize", op->tag);
 }
+
+// ================================================================================================================
+// Small kernels of the depth detector (DPT-Hybrid; reference depth_utils.py:11-32 loads it from
+// torch.hub "lewiji/MiDaS").  Its GEMM-shaped work runs on the igemm / flash kernels; these are the layout / pooling /
+// elementwise pieces around them.  Activations are channels-last fp16.
+
+// ResNetV2 stem: weight-standardised 7x7 stride-2 convolution with TF-"SAME" padding, 3 -> 64 channels, reading the NCHW
+// image directly (the only 3-channel tensor of the network) and writing channels-last.  One thread = one output pixel x 8
+// output channels; the 64 x 147 weights sit in LDS as [tap][channel] so a thread's 8 channels are one 16-byte read.
+__global__ __launch_bounds__(256) void stem7x7_kernel(const h16 *__restrict__ img, const h16 *__restrict__ w, h16 *__restrict__ out, int B,
+                                                      int H, int W, int Ho, int Wo, int pad_t, int pad_l) {
+    __shared__ __attribute__((aligned(16))) h16 ws[147 * 64];
+    for (int i = threadIdx.x; i < 147 * 64; i += 256) {
+        const int co = i & 63, tap = i >> 6;                 // tap = ci*49 + ky*7 + kx ; packed weight is [co][ci][ky][kx]
+        ws[i] = w[co * 147 + tap];
+    }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * Ho * Wo * 8;
+    if (idx >= total) return;
+    const int cg = (int)(idx & 7);
+    const long long pix = idx >> 3;
+    const int ox = (int)(pix % Wo);
+    const long long r = pix / Wo;
+    const int oy = (int)(r % Ho), b = (int)(r / Ho);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ci = 0; ci < 3; ++ci) {
+        const h16 *pl = img + ((long long)b * 3 + ci) * H * W;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = oy * 2 + ky - pad_t;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int ix = ox * 2 + kx - pad_l;
+                if (ix < 0 || ix >= W) continue;
+                const float x = (float)pl[(long long)iy * W + ix];
+                const h16x8 wv = l2d_ld8(ws + (ci * 49 + ky * 7 + kx) * 64 + cg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(x, (float)wv[e], acc[e]);
+            }
+        }
+    }
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)acc[e];
+    l2d_st8(out + pix * 64 + cg * 8, o);
+}
+
+int l2d_launch_stem7x7(const l2d_op *op, hipStream_t s) {
+    const int B = op->i[0], H = op->i[1], W = op->i[2];
+    if (!op->p[0] || !op->p[1] || !op->p[2] || B <= 0 || H <= 0 || W <= 0) {
+        l2d_set_error("stem7x7(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int th = (Ho - 1) * 2 + 7 - H, tw = (Wo - 1) * 2 + 7 - W;
+    const long long total = (long long)B * Ho * Wo * 8;
+    hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0], (const h16 *)op->p[1],
+                       (h16 *)op->p[2], B, H, W, Ho, Wo, (th > 0 ? th : 0) / 2, (tw > 0 ? tw : 0) / 2);
+    return l2d_check_launch("stem7x7", op->tag);
+}
+
+// pooling / sampling on channels-last tensors, one thread per (output pixel, 8 channels):
+//   mode 0: 3x3 stride-2 max pool with TF-"SAME" padding (window rows 2y-pad .. 2y-pad+2 that exist)
+//   mode 1: stride-2 subsample (the 1x1 stride-2 shortcut convolution's gather)
+//   mode 2: bilinear x2 upsample, align_corners=True (MiDaS Interpolate / FeatureFusionBlock)
+__global__ __launch_bounds__(256) void resample_nhwc_kernel(const h16 *__restrict__ in, h16 *__restrict__ out, int B, int H, int W, int C,
+                                                            int Ho, int Wo, int mode, int pad_t, int pad_l) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nvc = C / 8;
+    const long long total = (long long)B * Ho * Wo * nvc;
+    if (idx >= total) return;
+    const int vc = (int)(idx % nvc);
+    const long long pix = idx / nvc;
+    const int ox = (int)(pix % Wo);
+    const long long r = pix / Wo;
+    const int oy = (int)(r % Ho), b = (int)(r / Ho);
+    const h16 *src = in + (long long)b * H * W * C + vc * 8;
+    h16x8 o;
+    if (mode == 0) {
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 + ky - pad_t;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 + kx - pad_l;
+                if (ix < 0 || ix >= W) continue;
+                const h16x8 v = l2d_ld8(src + ((long long)iy * W + ix) * C);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (h16)m[e];
+    } else if (mode == 1) {
+        o = l2d_ld8(src + ((long long)(oy * 2) * W + ox * 2) * C);
+    } else {
+        const float sy = Ho > 1 ? (float)oy * (float)(H - 1) / (float)(Ho - 1) : 0.f;
+        const float sx = Wo > 1 ? (float)ox * (float)(W - 1) / (float)(Wo - 1) : 0.f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const h16x8 v00 = l2d_ld8(src + ((long long)y0 * W + x0) * C), v01 = l2d_ld8(src + ((long long)y0 * W + x1) * C);
+        const h16x8 v10 = l2d_ld8(src + ((long long)y1 * W + x0) * C), v11 = l2d_ld8(src + ((long long)y1 * W + x1) * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = (h16)((1.f - ly) * ((1.f - lx) * (float)v00[e] + lx * (float)v01[e]) + ly * ((1.f - lx) * (float)v10[e] + lx * (float)v11[e]));
+    }
+    l2d_st8(out + pix * C + vc * 8, o);
+}
+
+int l2d_launch_resample_nhwc(const l2d_op *op, hipStream_t s) {
+    const int B = op->i[0], H = op->i[1], W = op->i[2], C = op->i[3], mode = op->i[4];
+    if (!op->p[0] || !op->p[1] || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || mode < 0 || mode > 2) {
+        l2d_set_error("resample_nhwc(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    const int Ho = mode == 2 ? 2 * H : (H + 1) / 2, Wo = mode == 2 ? 2 * W : (W + 1) / 2;
+    const int th = (Ho - 1) * 2 + 3 - H, tw = (Wo - 1) * 2 + 3 - W;
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(resample_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0], (h16 *)op->p[1],
+                       B, H, W, C, Ho, Wo, mode, mode == 0 ? (th > 0 ? th : 0) / 2 : 0, mode == 0 ? (tw > 0 ? tw : 0) / 2 : 0);
+    return l2d_check_launch("resample_nhwc", op->tag);
+}
+
+// elementwise: s = a (+ b); out = s (if given); out_relu = relu(s) (if given).  The pre-activation residual conv units of the
+// DPT decoder need a tensor and its ReLU at the same time.
+__global__ __launch_bounds__(256) void ew_kernel(const h16 *__restrict__ a, const h16 *__restrict__ b, h16 *__restrict__ out,
+                                                 h16 *__restrict__ out_relu, long long n8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    h16x8 v = l2d_ld8(a + i * 8);
+    if (b) v = v + l2d_ld8(b + i * 8);
+    if (out) l2d_st8(out + i * 8, v);
+    if (out_relu) l2d_st8(out_relu + i * 8, __builtin_elementwise_max(v, l2d_zero8()));
+}
+
+int l2d_launch_ew(const l2d_op *op, hipStream_t s) {
+    const long long n = op->l[0];
+    if (!op->p[0] || (!op->p[2] && !op->p[3]) || n <= 0 || (n % 8)) {
+        l2d_set_error("ew(tag %d): invalid arguments", op->tag);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, (const h16 *)op->p[0], (const h16 *)op->p[1],
+                       (h16 *)op->p[2], (h16 *)op->p[3], n / 8);
+    return l2d_check_launch("ew", op->tag);
+}

@@ -54,6 +54,7 @@ struct IGemmArgs {
     // [sample][G][2]; T tokens per sample; (channels per group, channel offset in the consumer's concatenated axis) each
     unsigned long long *gn1, *gn2;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
+    int pad;   // low-side zero padding of the 3x3 gather: 1 (symmetric, nn.Conv2d padding=1) or 0 (TF-"SAME" of a stride-2 conv on an even size)
     long long sx1, sw, so, sres;
 };
 
@@ -91,6 +92,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
             if (rb) y += rb[n + r];
             if (a.epi == 2) y = l2d_silu(y);
             if (a.epi == 3) y = fmaxf(y, 0.f);
+            if (a.epi == 5) y = l2d_gelu(y);
             if (resp) y += (float)resp[(long long)m * a.ldr + n + r];
             if (a.epi == 4) y = fmaxf(y, 0.f);
             outp[(long long)m * a.ldo + n + r] = (h16)y;
@@ -106,6 +108,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, co
     if (a.epi == 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (a.epi == 5) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = l2d_gelu(v[r]);
     }
     if (resp) {
         h16x4 rr = *reinterpret_cast<const h16x4 *>(resp + (long long)m * a.ldr + n);
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             const int b = m / hw, rr = m - b * hw;
             const int oy = rr / a.Wout, ox = rr - oy * a.Wout;
             xb[j] = b; xy[j] = oy; xx[j] = ox;
-            const int iy0 = oy * a.stride - 1, ix0 = ox * a.stride - 1;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
             xoff[j] = (((long long)b * a.Hin + iy0) * a.Win + ix0) * a.ldx1 + xls[j];
             int mk = 0;
 #pragma unroll
@@ -278,8 +284,8 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             for (int j = 0; j < NIX; ++j) {
                 const int grp = j * 4 + wave;
                 const int c = is_cb + xls[j];
-                const int iy = xy[j] * a.stride + ky - 1;
-                const int ix = xx[j] * a.stride + kx - 1;
+                const int iy = xy[j] * a.stride + ky - a.pad;
+                const int ix = xx[j] * a.stride + kx - a.pad;
                 const bool ok = (m0 + (j * 4 + wave) * RPI + lrow < a.M) && c < Ctot && iy >= 0 && ix >= 0 &&
                                 iy < (a.Hin << a.ups) && ix < (a.Win << a.ups);
                 const long long pix = ((long long)xb[j] * a.Hin + (iy >> a.ups)) * a.Win + (ix >> a.ups);
@@ -463,6 +469,10 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
                     if (a.epi == 3) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if (a.epi == 5) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = l2d_gelu(v[r]);
                     }
                     h16x4 o;
 #pragma unroll
@@ -688,6 +698,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.gn1 = (unsigned long long *)op->p[9]; a.gn2 = (unsigned long long *)op->p[10];
+    a.pad = op->i[30] ? 0 : 1;        // i30 = 1: TF-"SAME" low-side padding 0 (stride-2 convs of the ResNetV2 backbone)
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     a.Kp = a.taps * a.CinP;
@@ -696,7 +707,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
-        a.epi < 0 || a.epi > 4 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
+        a.epi < 0 || a.epi > 5 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 10 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);

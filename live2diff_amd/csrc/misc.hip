@@ -40,7 +40,7 @@ int l2d_launch_timestep_embed(const l2d_op *op, hipStream_t s) {
 template <int MM>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(const h16 *__restrict__ A, const h16 *__restrict__ W,
                                                             const float *__restrict__ bias, void *__restrict__ out, int K,
-                                                            int Nout, int silu_out, int out_is_float, int ldo) {
+                                                            int Nout, int silu_out, int out_is_float, int ldo, long long lda) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= Nout) return;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const h16 *__restric
         h16x8 w = l2d_ld8(W + (long long)n * K + vc * 8);
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
-            h16x8 x = l2d_ld8(A + (long long)m * K + vc * 8);
+            h16x8 x = l2d_ld8(A + (long long)m * lda + vc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[m] += (float)w[e] * (float)x[e];
         }
@@ -74,14 +74,15 @@ int l2d_launch_skinny_linear(const l2d_op *op, hipStream_t s) {
     const float *bias = (const float *)op->p[2];
     void *out = op->p[3];
     int M = op->i[0], K = op->i[1], Nout = op->i[2], silu = op->i[3], isf = op->i[4], ldo = op->i[5];
-    if (!A || !W || !out || M <= 0 || M > 8 || K <= 0 || (K % 8) || Nout <= 0 || ldo < Nout) {
+    const long long lda = op->l[0] > 0 ? op->l[0] : K;       // row stride of A in halfs (0: dense)
+    if (!A || !W || !out || M <= 0 || M > 8 || K <= 0 || (K % 8) || Nout <= 0 || ldo < Nout || (lda % 8)) {
         l2d_set_error("skinny_linear(tag %d): invalid arguments (M=%d K=%d N=%d)", op->tag, M, K, Nout);
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
     dim3 grid((Nout + 3) / 4), block(256);
 #define L2D_SK(MMV) \
-    case MMV: hipLaunchKernelGGL((skinny_linear_kernel<MMV>), grid, block, 0, s, A, W, bias, out, K, Nout, silu, isf, ldo); break;
+    case MMV: hipLaunchKernelGGL((skinny_linear_kernel<MMV>), grid, block, 0, s, A, W, bias, out, K, Nout, silu, isf, ldo, lda); break;
     switch (M) {
         L2D_SK(1) L2D_SK(2) L2D_SK(3) L2D_SK(4) L2D_SK(5) L2D_SK(6) L2D_SK(7) L2D_SK(8)
     }

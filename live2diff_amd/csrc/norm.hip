@@ -17,6 +17,7 @@ struct GNArgs {
     h16 *out;
     int B, T, C1, C2, ld1, ld2, G, nchunk, silu;
     float eps;
+    const h16 *res;           // optional residual [B*T][C], added AFTER the normalisation and before the activation (act 3)
     const long long *acc;     // nchunk == 0: fixed-point statistics [B][G][2] accumulated by the producing GEMMs (igemm.hip)
 };
 
@@ -154,14 +155,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
             for (int u = 0; u < 4; ++u) {
                 const int tt = t + u * PR;
                 if (tt >= t1) break;
-                h16x8 o;
+                h16x8 o, rr = l2d_zero8();
+                const long long oidx = ((long long)b * a.T + tt) * C + vc * 8;
+                if (a.silu == 3) rr = l2d_ld8(a.res + oidx);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y = (float)v[u][e] * sc[e] + sh[e];
-                    if (a.silu) y = l2d_silu(y);
+                    if (a.silu == 1) y = l2d_silu(y);
+                    else if (a.silu == 2) y = fmaxf(y, 0.f);
+                    else if (a.silu == 3) y = fmaxf((float)(h16)y + (float)rr[e], 0.f);   // relu(norm(x) + shortcut): ResNetV2 bottleneck
                     o[e] = (h16)y;
                 }
-                l2d_st8(a.out + ((long long)b * a.T + tt) * C + vc * 8, o);
+                l2d_st8(a.out + oidx, o);
             }
         }
     }
@@ -173,11 +178,12 @@ static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
     a.B = op->i[0]; a.T = op->i[1]; a.C1 = op->i[2]; a.C2 = op->i[3]; a.ld1 = op->i[4]; a.ld2 = op->i[5];
     a.G = op->i[6]; a.nchunk = op->i[7]; a.silu = op->i[8]; a.eps = op->f[0];
     a.acc = (const long long *)op->p[6];
+    a.res = (const h16 *)op->p[7];
     int C = a.C1 + a.C2;
     if (apply && a.nchunk == 0 && a.acc) a.partial = (float *)a.acc;      // accumulator mode: no partial buffer
     if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 32 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
         (a.C2 > 0 && !a.x2) || a.nchunk < 0 || (a.nchunk == 0 && !(apply && a.acc)) || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
-        (apply && (!a.gamma || !a.beta || !a.out))) {
+        (apply && (!a.gamma || !a.beta || !a.out || a.silu < 0 || a.silu > 3 || (a.silu == 3 && !a.res)))) {
         l2d_set_error("groupnorm(tag %d): invalid arguments (B=%d T=%d C1=%d C2=%d G=%d nchunk=%d)", op->tag, a.B, a.T,
                       a.C1, a.C2, a.G, a.nchunk);
         return L2D_EINVAL;

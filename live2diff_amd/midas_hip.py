@@ -1,0 +1,432 @@
+"""HipMidas -- the depth detector of the per-frame path.
+
+Boundary (reference): `stream.depth_detector`, a `DPT_Hybrid` MiDaS model from torch.hub "lewiji/MiDaS"
+(live2diff/animatediff/models/depth_utils.py:11-32), called at pipeline_stream_animation_depth.py:553-558 as
+`depth_detector(images_384)` -> inverse depth `[B, 384, 384]`, and swappable like the UNet (TensorRT twin
+acceleration/tensorrt/engine.py:205-230, swap at wrapper.py:614-615); `.dtype` is read by the pipeline (:547).
+
+The network (122.4 M parameters: ResNetV2-50 stem + 3 stages with weight-standardised "SAME" convolutions and GroupNorm,
+12 ViT-B blocks on 24 x 24 patch tokens, DPT reassemble / fusion decoder; third-party -- parity unpinned, see
+oracle/midas_ref.py) maps onto the kernels the UNet and the VAE already use:
+  * every convolution / linear layer is an igemm launch on channels-last fp16 (weight standardisation is folded into the
+    packed weights once; the stride-2 "SAME" convs use the gather's low-side padding 0; bias, ReLU, GELU, residual adds are
+    epilogues); GroupNorm statistics come from the producing GEMM's epilogue, `gn_apply` fuses the ReLU and, at the end of a
+    bottleneck, `relu(norm(x) + shortcut)`;
+  * ViT attention = qk GEMM + V^T GEMM (operand roles swapped) + the flash kernel at d = 64 over 577 tokens; the value bias
+    is folded into the output projection's bias (softmax rows sum to 1: exact); the class token's share of the "project"
+    readout (`Linear(2C, C)` on [patch, cls]) is a per-image row bias from one skinny GEMM, the patch share an igemm + GELU;
+  * the patch-embedding GEMM adds the position embedding as its residual and writes straight into the token buffer behind
+    the (constant) class-token row;
+  * what is not GEMM-shaped: the 7x7 stem (direct kernel, reads the NCHW image), max pool, stride-2 subsample, align-corners
+    bilinear x2, and an add / ReLU elementwise kernel for the decoder's pre-activation residual units.
+One static plan per (batch, H, W), replayed through the C ABI.
+"""
+from types import SimpleNamespace
+from typing import Dict
+
+import torch
+
+from . import _lib, ops
+from .ops import round_up
+from .unet_hip import _Arena
+
+STAGES = (3, 4, 9)
+STAGE_CH = (256, 512, 1024)
+DIM, DEPTH, HEADS, MLP = 768, 12, 12, 3072
+HOOKS = (8, 11)
+FEAT, G = 256, 32
+
+
+def midas_param_spec(img: int = 384):
+    """MiDaS / timm state-dict names -> shapes of DPT-Hybrid (same inventory as oracle/midas_ref.py, kept in the product so that
+    it never imports the oracle; tests assert the two agree)."""
+    s = {}
+    bb = "pretrained.model.patch_embed.backbone."
+    s[bb + "stem.conv.weight"] = (64, 3, 7, 7)
+    s[bb + "stem.norm.weight"] = s[bb + "stem.norm.bias"] = (64,)
+    cin = 64
+    for si, (nb, cout) in enumerate(zip(STAGES, STAGE_CH)):
+        mid = cout // 4
+        for bi in range(nb):
+            p = bb + f"stages.{si}.blocks.{bi}."
+            if bi == 0:
+                s[p + "downsample.conv.weight"] = (cout, cin, 1, 1)
+                s[p + "downsample.norm.weight"] = s[p + "downsample.norm.bias"] = (cout,)
+            s[p + "conv1.weight"] = (mid, cin, 1, 1)
+            s[p + "norm1.weight"] = s[p + "norm1.bias"] = (mid,)
+            s[p + "conv2.weight"] = (mid, mid, 3, 3)
+            s[p + "norm2.weight"] = s[p + "norm2.bias"] = (mid,)
+            s[p + "conv3.weight"] = (cout, mid, 1, 1)
+            s[p + "norm3.weight"] = s[p + "norm3.bias"] = (cout,)
+            cin = cout
+    m = "pretrained.model."
+    s[m + "patch_embed.proj.weight"] = (DIM, STAGE_CH[-1], 1, 1)
+    s[m + "patch_embed.proj.bias"] = (DIM,)
+    s[m + "cls_token"] = (1, 1, DIM)
+    s[m + "pos_embed"] = (1, (img // 16) ** 2 + 1, DIM)
+    for i in range(DEPTH):
+        p = m + f"blocks.{i}."
+        s.update({p + "norm1.weight": (DIM,), p + "norm1.bias": (DIM,), p + "attn.qkv.weight": (3 * DIM, DIM), p + "attn.qkv.bias": (3 * DIM,),
+                  p + "attn.proj.weight": (DIM, DIM), p + "attn.proj.bias": (DIM,), p + "norm2.weight": (DIM,), p + "norm2.bias": (DIM,),
+                  p + "mlp.fc1.weight": (MLP, DIM), p + "mlp.fc1.bias": (MLP,), p + "mlp.fc2.weight": (DIM, MLP), p + "mlp.fc2.bias": (DIM,)})
+    for k in (3, 4):
+        p = f"pretrained.act_postprocess{k}."
+        s.update({p + "0.project.0.weight": (DIM, 2 * DIM), p + "0.project.0.bias": (DIM,), p + "3.weight": (DIM, DIM, 1, 1), p + "3.bias": (DIM,)})
+    s["pretrained.act_postprocess4.4.weight"] = (DIM, DIM, 3, 3)
+    s["pretrained.act_postprocess4.4.bias"] = (DIM,)
+    for k, c in zip((1, 2, 3, 4), (256, 512, DIM, DIM)):
+        s[f"scratch.layer{k}_rn.weight"] = (FEAT, c, 3, 3)
+    for k in (1, 2, 3, 4):
+        for u in (1, 2):
+            for c in (1, 2):
+                s[f"scratch.refinenet{k}.resConfUnit{u}.conv{c}.weight"] = (FEAT, FEAT, 3, 3)
+                s[f"scratch.refinenet{k}.resConfUnit{u}.conv{c}.bias"] = (FEAT,)
+        s[f"scratch.refinenet{k}.out_conv.weight"] = (FEAT, FEAT, 1, 1)
+        s[f"scratch.refinenet{k}.out_conv.bias"] = (FEAT,)
+    s.update({"scratch.output_conv.0.weight": (FEAT // 2, FEAT, 3, 3), "scratch.output_conv.0.bias": (FEAT // 2,),
+              "scratch.output_conv.2.weight": (32, FEAT // 2, 3, 3), "scratch.output_conv.2.bias": (32,),
+              "scratch.output_conv.4.weight": (1, 32, 1, 1), "scratch.output_conv.4.bias": (1,)})
+    return s
+
+
+def random_midas_state_dict(dtype=torch.float16, device="cpu", img: int = 384) -> Dict[str, torch.Tensor]:
+    """Key-hashed deterministic weights (seed = crc32(key)); token embeddings small, norms 1 +- 0.1, like the UNet's recipe."""
+    from .weights import _fill
+    out = {}
+    for k, shp in midas_param_spec(img).items():
+        if k.endswith(("cls_token", "pos_embed")):
+            out[k] = (0.02 * _fill("midas." + k + ".bias", shp, 1.0) / 0.05).to(device=device, dtype=dtype)
+        else:
+            out[k] = _fill("midas." + k, shp, 1.0).to(device=device, dtype=dtype)
+    return out
+
+
+def _standardize(w: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """timm StdConv2dSame: (w - mean) / sqrt(var + eps) per output channel, biased variance -- folded into the packed weights."""
+    wf = w.float()
+    mean = wf.mean(dim=(1, 2, 3), keepdim=True)
+    var = wf.var(dim=(1, 2, 3), keepdim=True, unbiased=False)
+    return (wf - mean) / torch.sqrt(var + eps)
+
+
+class HipMidas:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", img: int = 384, debug_taps: bool = False):
+        self.device = torch.device(device)
+        self.debug_taps = debug_taps        # tests: copy named intermediates out of the plan (stage-by-stage comparison)
+        self.dtype = torch.float16
+        self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()
+        spec = midas_param_spec(img)
+        missing = [k for k in spec if k not in state_dict]
+        if missing:
+            raise KeyError(f"DPT-Hybrid state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        g = lambda k: state_dict[k].to(self.device)
+        W = self.W = {}
+        bb = "pretrained.model.patch_embed.backbone."
+        W["stem.w"] = _standardize(g(bb + "stem.conv.weight")).to(torch.float16).contiguous()
+
+        def norm(name):
+            W[name + ".g"], W[name + ".beta"] = g(name + ".weight").to(torch.float16).contiguous(), g(name + ".bias").to(torch.float16).contiguous()
+
+        def conv(name, std=False, bias=True):
+            w = g(name + ".weight")
+            if std:
+                w = _standardize(w)
+            W[name + ".w"] = ops.pack_conv3x3(w) if w.shape[-1] == 3 else ops.pack_linear(w)
+            if bias and (name + ".bias") in state_dict:
+                W[name + ".b"] = ops.f32(g(name + ".bias"))
+
+        norm(bb + "stem.norm")
+        for si, nb in enumerate(STAGES):
+            for bi in range(nb):
+                p = bb + f"stages.{si}.blocks.{bi}."
+                if bi == 0:
+                    conv(p + "downsample.conv", std=True); norm(p + "downsample.norm")
+                for c in (1, 2, 3):
+                    conv(p + f"conv{c}", std=True); norm(p + f"norm{c}")
+        m = "pretrained.model."
+        conv(m + "patch_embed.proj")
+        pos = g(m + "pos_embed").float()[0]
+        W["pos_patches"] = pos[1:].to(torch.float16).contiguous()                         # residual of the patch-embedding GEMM
+        W["cls_row"] = (g(m + "cls_token").float()[0, 0] + pos[0]).to(torch.float16).contiguous()
+        for i in range(DEPTH):
+            p = m + f"blocks.{i}."
+            norm(p + "norm1"); norm(p + "norm2")
+            wqkv, bqkv = g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias").float()
+            W[p + "qk.w"] = ops.pack_linear(wqkv[: 2 * DIM])
+            W[p + "qk.b"] = bqkv[: 2 * DIM].contiguous()
+            W[p + "v.w"] = ops.pack_linear(wqkv[2 * DIM:])
+            wp = g(p + "attn.proj.weight")
+            W[p + "proj.w"] = ops.pack_linear(wp)
+            # attention rows sum to 1: attn(V + b_v) = attn(V) + b_v, so the value bias moves into the projection's bias
+            W[p + "proj.b"] = (g(p + "attn.proj.bias").float() + wp.float() @ bqkv[2 * DIM:]).contiguous()
+            conv(p + "mlp.fc1"); conv(p + "mlp.fc2")
+        for k in (3, 4):
+            p = f"pretrained.act_postprocess{k}."
+            wpr = g(p + "0.project.0.weight")
+            W[p + "proj_patch.w"] = ops.pack_linear(wpr[:, :DIM])
+            W[p + "proj_cls.w"] = wpr[:, DIM:].to(torch.float16).contiguous()
+            W[p + "proj.b"] = ops.f32(g(p + "0.project.0.bias"))
+            conv(p + "3")
+        conv("pretrained.act_postprocess4.4")
+        for k in (1, 2, 3, 4):
+            conv(f"scratch.layer{k}_rn", bias=False)
+            for u in (1, 2):
+                for c in (1, 2):
+                    conv(f"scratch.refinenet{k}.resConfUnit{u}.conv{c}")
+            conv(f"scratch.refinenet{k}.out_conv")
+        for j in (0, 2, 4):
+            conv(f"scratch.output_conv.{j}")
+        self._plans = {}
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ plan
+    def _build(self, B: int, H: int, W_: int):
+        if H % 32 or W_ % 32:
+            raise ValueError(f"DPT-Hybrid input {H}x{W_} must be a multiple of 32")
+        dev, W = self.device, self.W
+        ar = _Arena(dev)
+        pl = _lib.OpList()
+        st = SimpleNamespace(pl=pl, arena=ar, gn_layers=0)
+        st.inp = torch.zeros(B, 3, H, W_, dtype=torch.float16, device=dev)
+        st.gn_acc = torch.zeros(64, B, G, 2, dtype=torch.int64, device=dev)
+        st.gn_zero = torch.zeros_like(st.gn_acc)
+        zero_op = pl.append(*ops.copy(st.gn_zero, st.gn_acc, st.gn_acc.numel() * 8))
+        add = lambda opk: pl.append(*opk)
+        st.taps = {}
+
+        def tap(name, buf, *shape):
+            if self.debug_taps:
+                t = torch.zeros(*shape, dtype=torch.float16, device=dev)
+                add(ops.copy(buf, t, t.numel() * 2))
+                st.taps[name] = t
+
+        def gemm(x, wt, out, **kw):
+            taps = kw.get("taps", 1)
+            tile, S, variant = ops.igemm_schedule(kw["M"], kw["Nout"], taps * kw["CinP"], kw.get("batch", 1), kw.get("epi", 0), taps)
+            if variant in (6, 7) and kw["CinP"] % 128:
+                variant = 1
+            if tile == 1 and variant in (7, 8, 9):
+                variant = 5
+            ws = ar.alloc(kw.get("batch", 1) * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
+            op = add(ops.igemm(x, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
+            ar.release(ws)
+            return op
+
+        def lin(x, M, K, name, out=None, bias=True, epi=0, res=None, ldr=0, **kw):
+            wt = W[name + ".w"]
+            n = wt.shape[0]
+            out = ar.alloc(M * max(4, n)) if out is None else out
+            op = gemm(x, wt, out, M=M, Nout=n, C1=K, ldx1=K, CinP=wt.shape[1], ldo=max(4, n), bias=(W.get(name + ".b") if bias else None),
+                      epi=epi, res=res, ldr=ldr, **kw)
+            return out, op
+
+        def conv3(x, C, h, w, name, stride=1, same=False, epi=0, res=None, bias=True):
+            wt = W[name + ".w"]
+            n = wt.shape[0]
+            ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+            out = ar.alloc(B * ho * wo * n)
+            op = gemm(x, wt, out, M=B * ho * wo, Nout=n, C1=C, ldx1=C, CinP=wt.shape[1] // 9, ldo=n, bias=(W.get(name + ".b") if bias else None),
+                      res=res, ldr=(n if res is not None else 0), taps=9, B=B, Hin=h, Win=w, Hout=ho, Wout=wo, stride=stride, epi=epi,
+                      pad_same=same)
+            return out, op, ho, wo
+
+        def gnorm(x, op_prod, C, T, name, act, res=None):
+            """GroupNorm(32) (+ ReLU / + shortcut + ReLU) of a tensor just written by `op_prod` (statistics from its epilogue)."""
+            out = ar.alloc(B * T * C)
+            acc_ptr = st.gn_acc.data_ptr() + st.gn_layers * B * G * 2 * 8
+            if st.gn_layers < st.gn_acc.shape[0] and ops.igemm_gn_target(op_prod, acc_ptr, T=T, G=G, cpg=C // G, choff=0):
+                st.gn_layers += 1
+                add(ops.gn_apply(x, None, W[name + ".g"], W[name + ".beta"], out, eps=1e-5, silu=act, B=B, T=T, C1=C, ld1=C, G=G, nchunk=0,
+                                 acc_ptr=acc_ptr, res=res))
+            else:
+                nchunk = max(1, min(64, T // 16))
+                partial = ar.alloc(B * nchunk * G * 2, torch.float32)
+                kw = dict(B=B, T=T, C1=C, ld1=C, G=G, nchunk=nchunk)
+                add(ops.gn_stats(x, partial, **kw))
+                add(ops.gn_apply(x, partial, W[name + ".g"], W[name + ".beta"], out, eps=1e-5, silu=act, res=res, **kw))
+                ar.release(partial)
+            return out
+
+        # ---- ResNetV2 stem: 7x7 s2 (std, SAME) -> GN + ReLU -> 3x3 s2 max pool (SAME)
+        h, w = (H + 1) // 2, (W_ + 1) // 2
+        y = ar.alloc(B * h * w * 64)
+        add(ops.stem7x7(st.inp, W["stem.w"], y, B=B, H=H, W=W_))
+        bb = "pretrained.model.patch_embed.backbone."
+        nchunk = 64
+        partial = ar.alloc(B * nchunk * G * 2, torch.float32)
+        kw = dict(B=B, T=h * w, C1=64, ld1=64, G=G, nchunk=nchunk)
+        add(ops.gn_stats(y, partial, **kw))
+        yn = ar.alloc(B * h * w * 64)
+        add(ops.gn_apply(y, partial, W[bb + "stem.norm.g"], W[bb + "stem.norm.beta"], yn, eps=1e-5, silu=ops.ACT_RELU, **kw))
+        ar.release(partial); ar.release(y)
+        h2, w2 = (h + 1) // 2, (w + 1) // 2
+        x = ar.alloc(B * h2 * w2 * 64)
+        add(ops.resample_nhwc(yn, x, B=B, H=h, W=w, C=64, mode=ops.RS_MAXPOOL))
+        ar.release(yn)
+        h, w, C = h2, w2, 64
+        tap("stem", x, B, h, w, C)
+
+        # ---- stages of bottlenecks
+        feats = []
+        for si, (nb, cout) in enumerate(zip(STAGES, STAGE_CH)):
+            mid = cout // 4
+            for bi in range(nb):
+                p = bb + f"stages.{si}.blocks.{bi}."
+                stride = 2 if (bi == 0 and si > 0) else 1
+                ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+                if bi == 0:
+                    xs = x
+                    if stride == 2:
+                        xs = ar.alloc(B * ho * wo * C)
+                        add(ops.resample_nhwc(x, xs, B=B, H=h, W=w, C=C, mode=ops.RS_SUBSAMPLE))
+                    sc_raw, op = lin(xs, B * ho * wo, C, p + "downsample.conv", bias=False)
+                    sc = gnorm(sc_raw, op, cout, ho * wo, p + "downsample.norm", ops.ACT_NONE)
+                    ar.release(sc_raw)
+                    if xs is not x:
+                        ar.release(xs)
+                else:
+                    sc = x
+                a1, op = lin(x, B * h * w, C, p + "conv1", bias=False)
+                n1 = gnorm(a1, op, mid, h * w, p + "norm1", ops.ACT_RELU); ar.release(a1)
+                a2, op, _, _ = conv3(n1, mid, h, w, p + "conv2", stride=stride, same=(stride == 2), bias=False); ar.release(n1)
+                n2 = gnorm(a2, op, mid, ho * wo, p + "norm2", ops.ACT_RELU); ar.release(a2)
+                a3, op = lin(n2, B * ho * wo, mid, p + "conv3", bias=False); ar.release(n2)
+                out = gnorm(a3, op, cout, ho * wo, p + "norm3", ops.ACT_ADD_RELU, res=sc); ar.release(a3)
+                if sc is not x:
+                    ar.release(sc)
+                if not any(x is f[0] for f in feats[:2]):     # the outputs of stages 0 / 1 stay alive: the decoder taps them
+                    ar.release(x)
+                x, h, w, C = out, ho, wo, cout
+            feats.append((x, C, h, w))
+            tap(f"stage{si}", x, B, h, w, C)
+
+        # ---- patch embedding -> tokens [B][1 + g*g][768]: row 0 = cls + pos[0] (constant), rows 1.. = proj(x) + pos[1:]
+        gh, gw = h, w
+        T = gh * gw + 1
+        m = "pretrained.model."
+        st.tok0 = torch.zeros(B, T, DIM, dtype=torch.float16, device=dev)
+        st.tok0[:, 0] = W["cls_row"]
+        wt = W[m + "patch_embed.proj.w"]
+        gemm(x, wt, st.tok0, M=gh * gw, Nout=DIM, C1=C, ldx1=C, CinP=wt.shape[1], ldo=DIM, bias=W[m + "patch_embed.proj.b"], res=W["pos_patches"],
+             ldr=DIM, batch=B, sx1=gh * gw * C, sw=0, so=T * DIM, sres=0, out_off=DIM)
+        tok, hooked = st.tok0, {}
+        d = DIM // HEADS
+        for i in range(DEPTH):
+            p = m + f"blocks.{i}."
+            n1 = ar.alloc(B * T * DIM)
+            add(ops.layernorm(tok, W[p + "norm1.g"], W[p + "norm1.beta"], n1, rows=B * T, C=DIM, ldx=DIM, ldo=DIM, eps=1e-6))
+            qk, _ = lin(n1, B * T, DIM, p + "qk")
+            ldvt = round_up(T, 8)
+            vt = torch.zeros(B * DIM * ldvt, dtype=torch.float16, device=dev) if i == 0 else st.vt   # padding columns stay finite
+            st.vt = vt
+            wv = W[p + "v.w"]
+            gemm(wv, n1, vt, M=DIM, Nout=T, C1=DIM, ldx1=wv.shape[1], CinP=DIM, ldo=ldvt, batch=B, sx1=0, sw=T * DIM, so=DIM * ldvt)
+            ar.release(n1)
+            ao = ar.alloc(B * T * DIM)
+            add(ops.flash_attn(qk, qk, vt, ao, B=B, H=HEADS, d=d, Tq=T, Tk=T, ldq=2 * DIM, ldk=2 * DIM, ldvt=ldvt, ldo=DIM, sq=T * 2 * DIM,
+                               sk=T * 2 * DIM, svt=DIM * ldvt, so=T * DIM, k_off=DIM))
+            ar.release(qk)
+            t2, _ = lin(ao, B * T, DIM, p + "proj", res=tok, ldr=DIM); ar.release(ao)
+            if tok is not st.tok0 and not any(tok is v for v in hooked.values()):
+                ar.release(tok)
+            n2 = ar.alloc(B * T * DIM)
+            add(ops.layernorm(t2, W[p + "norm2.g"], W[p + "norm2.beta"], n2, rows=B * T, C=DIM, ldx=DIM, ldo=DIM, eps=1e-6))
+            hid, _ = lin(n2, B * T, DIM, p + "mlp.fc1", epi=5); ar.release(n2)
+            t3, _ = lin(hid, B * T, MLP, p + "mlp.fc2", res=t2, ldr=DIM); ar.release(hid); ar.release(t2)
+            tok = t3
+            if i in HOOKS:
+                hooked[i] = tok
+                tap(f"vit{i}", tok, B, T, DIM)
+
+        # ---- reassemble taps 3 / 4: "project" readout (class token as a per-image row bias) -> 1x1 conv (-> 3x3 s2)
+        def readout(tokens, k):
+            p = f"pretrained.act_postprocess{k}."
+            rb = torch.zeros(B, DIM, dtype=torch.float32, device=dev)
+            add(ops.skinny_linear(tokens, W[p + "proj_cls.w"], W[p + "proj.b"], rb, M=B, K=DIM, Nout=DIM, lda=T * DIM))
+            f = ar.alloc(B * gh * gw * DIM)
+            wt = W[p + "proj_patch.w"]
+            for b in range(B):            # one launch per image: the row bias is per image
+                op = gemm(tokens, wt, f, M=gh * gw, Nout=DIM, C1=DIM, ldx1=DIM, CinP=wt.shape[1], ldo=DIM, rowbias=rb, ldrb=DIM,
+                          rows_per_bias=gh * gw, epi=5, x1_off=(b * T + 1) * DIM, out_off=b * gh * gw * DIM)
+                op.p[4] = rb.data_ptr() + 4 * b * DIM
+            o, _ = lin(f, B * gh * gw, DIM, p + "3"); ar.release(f)
+            return o
+        l3 = readout(hooked[HOOKS[0]], 3)
+        l4a = readout(hooked[HOOKS[1]], 4)
+        l4, _, h4, w4 = conv3(l4a, DIM, gh, gw, "pretrained.act_postprocess4.4", stride=2); ar.release(l4a)
+        for v in hooked.values():
+            ar.release(v)
+        tap("l3", l3, B, gh, gw, DIM)
+        tap("l4", l4, B, h4, w4, DIM)
+
+        # ---- decoder
+        (l1, c1, h1, w1), (l2, c2, h2_, w2_) = feats[0], feats[1]
+        r1, _, _, _ = conv3(l1, c1, h1, w1, "scratch.layer1_rn", bias=False); ar.release(l1)
+        r2, _, _, _ = conv3(l2, c2, h2_, w2_, "scratch.layer2_rn", bias=False); ar.release(l2)
+        r3, _, _, _ = conv3(l3, DIM, gh, gw, "scratch.layer3_rn", bias=False); ar.release(l3)
+        r4, _, _, _ = conv3(l4, DIM, h4, w4, "scratch.layer4_rn", bias=False); ar.release(l4)
+
+        def rcu(x, xr, hh, ww, p):
+            """conv2(relu(conv1(relu(x)))) + x ; xr = relu(x) (precomputed)"""
+            a1, _, _, _ = conv3(xr, FEAT, hh, ww, p + "conv1", epi=3)
+            o, _, _, _ = conv3(a1, FEAT, hh, ww, p + "conv2", res=x); ar.release(a1)
+            return o
+
+        def fuse(k, x, hh, ww, skip=None):
+            p = f"scratch.refinenet{k}."
+            n = B * hh * ww * FEAT
+            if skip is not None:
+                sr = ar.alloc(n)
+                add(ops.ew(skip, None, None, sr, n=n))
+                t = rcu(skip, sr, hh, ww, p + "resConfUnit1."); ar.release(sr); ar.release(skip)
+                out, outr = ar.alloc(n), ar.alloc(n)
+                add(ops.ew(x, t, out, outr, n=n)); ar.release(t); ar.release(x)
+            else:
+                out, outr = x, ar.alloc(n)
+                add(ops.ew(x, None, None, outr, n=n))
+            o2 = rcu(out, outr, hh, ww, p + "resConfUnit2."); ar.release(out); ar.release(outr)
+            up = ar.alloc(4 * n)
+            add(ops.resample_nhwc(o2, up, B=B, H=hh, W=ww, C=FEAT, mode=ops.RS_UP2X)); ar.release(o2)
+            o, _ = lin(up, 4 * B * hh * ww, FEAT, p + "out_conv"); ar.release(up)
+            tap(f"path{k}", o, B, 2 * hh, 2 * ww, FEAT)
+            return o, 2 * hh, 2 * ww
+        path, hh, ww = fuse(4, r4, h4, w4)
+        path, hh, ww = fuse(3, path, hh, ww, r3)
+        path, hh, ww = fuse(2, path, hh, ww, r2)
+        path, hh, ww = fuse(1, path, hh, ww, r1)
+
+        # ---- head: conv3x3 256 -> 128, bilinear x2, conv3x3 128 -> 32 + ReLU, conv1x1 32 -> 1 + ReLU
+        o, _, _, _ = conv3(path, FEAT, hh, ww, "scratch.output_conv.0"); ar.release(path)
+        up = ar.alloc(4 * B * hh * ww * (FEAT // 2))
+        add(ops.resample_nhwc(o, up, B=B, H=hh, W=ww, C=FEAT // 2, mode=ops.RS_UP2X)); ar.release(o)
+        hh, ww = 2 * hh, 2 * ww
+        o, _, _, _ = conv3(up, FEAT // 2, hh, ww, "scratch.output_conv.2", epi=3); ar.release(up)
+        d1, _ = lin(o, B * hh * ww, 32, "scratch.output_conv.4", epi=3); ar.release(o)       # [M][4], channel 0
+        st.out = torch.zeros(B, 1, hh * ww, dtype=torch.float16, device=dev)
+        add(ops.nhwc_to_nchw(d1, st.out, B=B, C=1, HW=hh * ww, ld=4))
+        st.out_shape = (B, hh, ww)
+        zero_op.l[0] = max(16, st.gn_layers * B * G * 2 * 8)
+        st.arena_bytes = ar.nbytes()
+        return st
+
+    @torch.no_grad()
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        """images [B,3,H,W] fp16 (the reference feeds 384 x 384) -> inverse depth [B,H,W] fp16 >= 0 (a view of the plan's static
+        output buffer, valid until the next call with the same shape)."""
+        B, C, H, W_ = images.shape
+        if C != 3:
+            raise ValueError(f"depth detector expects [B,3,H,W], got {tuple(images.shape)}")
+        st = self._plans.get((B, H, W_))
+        if st is None:
+            st = self._plans[(B, H, W_)] = self._build(B, H, W_)
+        st.inp.copy_(images)
+        st.pl.run()
+        return st.out.view(st.out_shape)
+
+    def plan_summary(self):
+        return {k: dict(n_ops=len(st.pl), gn_fused=st.gn_layers, arena_bytes=st.arena_bytes) for k, st in self._plans.items()}

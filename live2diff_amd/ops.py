@@ -157,7 +157,7 @@ _TUNED = _load_tuned()
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5, order=0):
+          variant=5, order=0, pad_same=False):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
     splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
     op = L2dOp()
@@ -185,6 +185,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
     for j, v in enumerate(vals):
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
+    op.i[30] = 1 if pad_same else 0       # TF-"SAME" low-side padding 0 (stride-2 3x3 convs of the ResNetV2 backbone)
     return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
 
 
@@ -197,7 +198,10 @@ def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):
     return op, (x1, x2, partial)
 
 
-def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0, acc_ptr=None):
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_ADD_RELU = 0, 1, 2, 3
+
+
+def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0, acc_ptr=None, res=None):
     """nchunk = 0 + acc_ptr: the statistics come from the fixed-point accumulators [B][G][2] int64 that the producing igemm
     launches filled (igemm `gn_target`), `partial` is unused (None)."""
     op = L2dOp()
@@ -207,10 +211,12 @@ def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, si
         assert nchunk == 0
         op.p[6] = int(acc_ptr)
     op.p[3], op.p[4], op.p[5] = _ptr(_h(gamma)), _ptr(_h(beta)), _ptr(_h(out))
-    for j, v in enumerate([B, T, C1, C2, ld1, ld2, G, nchunk, 1 if silu else 0]):
+    for j, v in enumerate([B, T, C1, C2, ld1, ld2, G, nchunk, int(silu)]):     # silu: bool, or an ACT_* code
         op.i[j] = int(v)
     op.f[0] = float(eps)
-    return op, (x1, x2, partial, gamma, beta, out)
+    if res is not None:
+        op.p[7] = _ptr(_h(res))
+    return op, (x1, x2, partial, gamma, beta, out, res)
 
 
 def layernorm(x, gamma, beta, out, *, rows, C, ldx, ldo, eps=1e-5):
@@ -269,10 +275,11 @@ def tattn_warmup(qkv, cache_row, q_pe, k_pe, v_pe, out, *, F, T, C, L, H):
     return op, (qkv, cache_row, q_pe, k_pe, v_pe, out)
 
 
-def skinny_linear(a, w, bias, out, *, M, K, Nout, silu_out=False, ldo=None):
+def skinny_linear(a, w, bias, out, *, M, K, Nout, silu_out=False, ldo=None, lda=0, a_off=0):
     op = L2dOp()
     op.kind = _lib.OP_SKINNY_LINEAR
-    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(a)), _ptr(_h(w)), _ptr(bias), _ptr(out)
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(a)) + 2 * a_off, _ptr(_h(w)), _ptr(bias), _ptr(out)
+    op.l[0] = int(lda)
     is_f = out.dtype == torch.float32
     for j, v in enumerate([M, K, Nout, 1 if silu_out else 0, 1 if is_f else 0, ldo if ldo is not None else Nout]):
         op.i[j] = int(v)
@@ -309,6 +316,36 @@ def nhwc_to_nchw(x, out, *, B, C, HW, ld, mode=MAP_COPY, a=1.0, b=0.0):
         op.i[j] = int(v)
     op.f[0], op.f[1] = float(a), float(b)
     return op, (x, out)
+
+
+def stem7x7(img, w, out, *, B, H, W):
+    """weight-standardised 7x7 stride-2 SAME conv 3 -> 64 from the NCHW image to channels-last (DPT-Hybrid stem)."""
+    op = L2dOp()
+    op.kind = _lib.OP_STEM7X7
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(img)), _ptr(_h(w)), _ptr(_h(out))
+    op.i[0], op.i[1], op.i[2] = int(B), int(H), int(W)
+    return op, (img, w, out)
+
+
+RS_MAXPOOL, RS_SUBSAMPLE, RS_UP2X = 0, 1, 2
+
+
+def resample_nhwc(x, out, *, B, H, W, C, mode):
+    op = L2dOp()
+    op.kind = _lib.OP_RESAMPLE_NHWC
+    op.p[0], op.p[1] = _ptr(_h(x)), _ptr(_h(out))
+    for j, v in enumerate([B, H, W, C, mode]):
+        op.i[j] = int(v)
+    return op, (x, out)
+
+
+def ew(a, b, out, out_relu, *, n):
+    """s = a (+ b); out = s; out_relu = relu(s) (either output may be None)."""
+    op = L2dOp()
+    op.kind = _lib.OP_EW
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(a)), _ptr(b), _ptr(out), _ptr(out_relu)
+    op.l[0] = int(n)
+    return op, (a, b, out, out_relu)
 
 
 def resize_bilinear(x, out, *, planes, Hin, Win, Hout, Wout):

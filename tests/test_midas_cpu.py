@@ -1,0 +1,87 @@
+"""CPU tests (-m "not gpu") of the depth detector's host side: parameter inventory, plan validation without
+a device, weight folding identities, and the oracle's own invariants (oracle/midas_ref.py restates a third-party topology:
+parity unpinned)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+@pytest.fixture()
+def dry_run():
+    from live2diff_amd import _lib
+    _lib.set_dry_run(True)
+    yield
+    _lib.set_dry_run(False)
+
+
+def test_midas_spec_matches_oracle_and_published_size():
+    from live2diff_amd.midas_hip import midas_param_spec
+    from oracle import midas_ref as M
+    spec = midas_param_spec()
+    assert dict(M.midas_param_spec()) == spec and len(spec) == 364
+    n = sum(torch.Size(s).numel() for s in spec.values())
+    assert 122e6 < n < 124e6                                   # DPT-Hybrid: ~123 M parameters
+    assert spec["pretrained.model.pos_embed"] == (1, 577, 768) and spec["scratch.output_conv.4.weight"] == (1, 32, 1, 1)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 384, 384), (2, 384, 384), (3, 128, 128)])
+def test_midas_plan_validates_without_gpu(dry_run, B, H, W):
+    from live2diff_amd.midas_hip import HipMidas, midas_param_spec
+    sd = {k: torch.zeros(s, dtype=torch.float16) for k, s in midas_param_spec(H).items()}      # pos_embed is sized for H x H inputs
+    m = HipMidas(sd, device="cpu", img=H)
+    d = m(torch.zeros(B, 3, H, W, dtype=torch.float16))
+    assert d.shape == (B, H, W) and d.dtype == torch.float16 and m.dtype == torch.float16 and m.to("cuda") is m
+    s = m.plan_summary()[(B, H, W)]
+    # 16 bottlenecks x 3 norms + 3 downsample norms take their statistics from the producing GEMM; only the stem norm runs
+    # the statistics kernel
+    assert s["n_ops"] <= 260 + 2 * (B - 1) + 2 * (51 - s["gn_fused"])
+    if H == 384:
+        assert s["gn_fused"] == 51
+    with pytest.raises(ValueError):
+        m(torch.zeros(B, 3, 100, 100, dtype=torch.float16))
+    with pytest.raises(KeyError):
+        HipMidas({k: v for k, v in sd.items() if "refinenet2" not in k}, device="cpu")
+
+
+def test_value_bias_folds_into_projection_bias():
+    """softmax rows sum to 1, so attn @ (V + b_v) = attn @ V + b_v: HipMidas moves b_v through the output projection."""
+    g = torch.Generator().manual_seed(0)
+    T, C = 9, 16
+    att = torch.softmax(torch.randn(T, T, generator=g), -1)
+    v, bv, wp, bp = torch.randn(T, C, generator=g), torch.randn(C, generator=g), torch.randn(C, C, generator=g), torch.randn(C, generator=g)
+    ref = F.linear(att @ (v + bv), wp, bp)
+    got = F.linear(att @ v, wp, bp + wp @ bv)
+    assert torch.allclose(ref, got, atol=1e-5)
+
+
+def test_oracle_same_padding_and_weight_standardisation():
+    from oracle import midas_ref as M
+    assert M.same_pad(384, 7, 2) == (2, 3) and M.same_pad(192, 3, 2) == (0, 1) and M.same_pad(96, 3, 1) == (1, 1)
+    assert M.same_pad(96, 1, 2) == (0, 0)
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(8, 4, 3, 3, generator=g) * 3 + 1
+    x = torch.randn(1, 4, 10, 10, generator=g)
+    y = M.std_conv_same(x, w, 2)
+    assert y.shape == (1, 8, 5, 5)
+    # standardisation makes the conv invariant to an affine change of the raw weights
+    assert torch.allclose(y, M.std_conv_same(x, w * 5 - 2, 2), atol=1e-4)
+    from live2diff_amd.midas_hip import _standardize
+    ws = _standardize(w)
+    assert torch.allclose(ws.mean(dim=(1, 2, 3)), torch.zeros(8), atol=1e-6) and torch.allclose(ws.var(dim=(1, 2, 3), unbiased=False), torch.ones(8), atol=1e-4)
+    assert torch.allclose(y, F.conv2d(F.pad(x, (0, 1, 0, 1)), ws, stride=2), atol=1e-5)
+
+
+def test_oracle_forward_small_input_properties():
+    """64 x 64 input (4 x 4 patch grid): output shape, non-negativity, batch independence, taps recorded."""
+    from oracle import midas_ref as M
+    from live2diff_amd.midas_hip import random_midas_state_dict
+    sd = random_midas_state_dict(dtype=torch.float32, img=64)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    taps = {}
+    y = M.midas_forward(x, sd, taps)
+    assert y.shape == (2, 64, 64) and (y >= 0).all() and torch.isfinite(y).all()
+    assert taps["stage0"].shape == (2, 256, 16, 16) and taps["stage2"].shape == (2, 1024, 4, 4) and taps["vit11"].shape == (2, 17, 768)
+    assert taps["l4"].shape == (2, 768, 2, 2) and taps["path1"].shape == (2, 256, 32, 32)
+    y1 = M.midas_forward(x[1:], sd)
+    assert torch.allclose(y[1:], y1, rtol=1e-4, atol=1e-4 * float(y.abs().max()))

@@ -1,0 +1,14 @@
+# round-end evidence: full GPU suite, bench line + kernel trace + frame trace + traffic counters, PMC pass over the kernels,
+# the other BASELINE configurations
+TAG=${1:-r2z}
+mkdir -p gpurun_out/$TAG
+(timeout 1100 python -m pytest tests -m gpu -q --durations=10 > gpurun_out/$TAG/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$TAG/pytest.log); tail -16 gpurun_out/$TAG/pytest.log
+timeout 900 bash tools/profile_round.sh $TAG > gpurun_out/$TAG/profile_round.log 2>&1; tail -30 gpurun_out/$TAG/profile_round.log
+export TMPDIR=/tmp
+timeout 300 bash tools/pmc_ops.sh gpurun_out/$TAG/${TAG}_pmc_ops.txt > gpurun_out/$TAG/pmc_ops.log 2>&1; tail -2 gpurun_out/$TAG/pmc_ops.log
+for cfgs in "256 256 1 12" "512 768 2 24" "512 512 4 16" "576 1024 2 40"; do set -- $cfgs
+  timeout 300 python bench.py --height $1 --width $2 --denoise-steps $3 --window $4 --steps 20 --warmup 5 --no-cpu-baseline --breakdown 0 > gpurun_out/$TAG/bench_$1x$2_n$3_L$4.json 2>> gpurun_out/$TAG/bench_other.err
+  python -c "
+import json
+d=json.loads(open('gpurun_out/$TAG/bench_$1x$2_n$3_L$4.json').read().strip().splitlines()[-1]); print(d['config']['workload'][:60], d['value'], d['ms_per_step'], d['config']['kv_cache_GB_per_stream'], (d.get('whole_frame') or {}).get('frames_per_s'))"
+done
