@@ -261,7 +261,7 @@ def main():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--sink", type=int, default=0, help="warm-up / sink slots (default 8; 4 with --window 12 = BASELINE configs[0])")
     ap.add_argument("--breakdown", type=int, default=1)
-    ap.add_argument("--whole-frame", type=int, default=1, help="also time VAE encode x2 + depth glue + UNet + VAE decode (informational)")
+    ap.add_argument("--whole-frame", type=int, default=1, help="also time VAE encode x2 + depth detector and glue + UNet + VAE decode (informational)")
     ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
     ap.add_argument("--dump-plan", type=str, default="", help="write the stream plan (one row per launch) as CSV")
     ap.add_argument("--device-step", type=int, default=0,
@@ -373,21 +373,22 @@ def main():
         except Exception as e:  # noqa: BLE001
             latency = {"error": str(e)}
 
-    # ---- whole frame (informational, SURVEY 8f rows F1 / F2-glue): what the published FPS figures include around the UNet --
-    # TAESD encode of the frame, the depth path's glue + TAESD encode of the depth map, the UNet step, TAESD decode.  The
-    # depth DETECTOR itself (MiDaS, row F2) is the caller's object and is replaced by a fixed depth map here.
+    # ---- whole frame (informational, SURVEY 8f rows F1 / F2): what the published FPS figures include around the UNet --
+    # TAESD encode of the frame, the depth path (384x384 resize, DPT-Hybrid depth detector, min-max + resize, TAESD encode of
+    # the depth map), the UNet step, TAESD decode.  Random-init weights of the published architectures throughout.
     whole = None
     if rank == 0 and args.whole_frame and dstep is None and (args.height % 8 == 0 and args.width % 8 == 0):
         try:
+            from live2diff_amd.midas_hip import HipMidas, random_midas_state_dict
             from live2diff_amd.vae_hip import HipDepthGlue, HipTinyVAE, random_taesd_state_dict
             vae = HipTinyVAE(random_taesd_state_dict(device=dev), device=dev)
             glue = HipDepthGlue(dev)
+            detector = HipMidas(random_midas_state_dict(device=dev), device=dev)
             img = torch.rand(1, 3, args.height, args.width, generator=g, device=dev, dtype=torch.float16) * 2 - 1
-            dmap = (torch.rand(1, 384, 384, generator=g, device=dev, dtype=torch.float32) * 5 + 3).half()
 
             def frame():
                 lat = vae.encode(img).latents
-                _ = glue.resize(img, 384, 384)                                   # the depth detector's input (detector: external)
+                dmap = detector(glue.resize(img, 384, 384))
                 dlat = vae.encode(glue.normalize_resize(dmap, args.height, args.width)).latents
                 x[:1].copy_(lat.view(1, 4, 1, h, w))
                 d[:1].copy_(dlat.view(1, 4, 1, h, w))
@@ -403,9 +404,10 @@ def main():
             torch.cuda.synchronize()
             tw = (time.perf_counter() - tw) / nw
             whole = {"frames_per_s": round(1.0 / tw, 2), "ms_per_frame": round(1e3 * tw, 3), "finite": bool(torch.isfinite(im).all()),
-                     "includes": "TAESD encode (frame) + depth glue (384x384 resize, min-max, resize) + TAESD encode (depth map) + "
-                                 "UNet step + TAESD decode", "excludes": "MiDaS depth detector (caller-owned), text encoder",
-                     "vae_launches": {str(k): v_["n_ops"] for k, v_ in vae.plan_summary().items()}}
+                     "includes": "TAESD encode (frame) + 384x384 resize + DPT-Hybrid depth detector + min-max / resize + TAESD encode "
+                                 "(depth map) + UNet step + TAESD decode", "excludes": "text encoder (runs once per prompt)",
+                     "vae_launches": {str(k): v_["n_ops"] for k, v_ in vae.plan_summary().items()},
+                     "depth_detector_launches": {str(k): v_["n_ops"] for k, v_ in detector.plan_summary().items()}}
         except Exception as e:  # noqa: BLE001  -- informational figure: never fails the benchmark
             whole = {"error": repr(e)}
 

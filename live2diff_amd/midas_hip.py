@@ -1,9 +1,10 @@
 """HipMidas -- the depth detector of the per-frame path.
 
-Boundary (reference): `stream.depth_detector`, a `DPT_Hybrid` MiDaS model from torch.hub "lewiji/MiDaS"
-(live2diff/animatediff/models/depth_utils.py:11-32), called at pipeline_stream_animation_depth.py:553-558 as
-`depth_detector(images_384)` -> inverse depth `[B, 384, 384]`, and swappable like the UNet (TensorRT twin
-acceleration/tensorrt/engine.py:205-230, swap at wrapper.py:614-615); `.dtype` is read by the pipeline (:547).
+Boundary (reference): `stream.depth_detector` = `MidasDetector` (live2diff/animatediff/models/depth_utils.py:11-32), a thin
+wrapper around `DPTDepthModel(backbone="vitb_rn50_384", non_negative=True)` from the un-vendored `live2diff/MiDaS`
+submodule; called at pipeline_stream_animation_depth.py:563 as `depth_detector(images_384)` -> inverse depth `[B, 384, 384]`
+and swappable like the UNet (TensorRT twin `MidasEngine`, swap at wrapper.py:611-615, which also re-attaches `.dtype`, read by
+the pipeline at :550).  State-dict keys are MiDaS / timm names, with or without the wrapper's `model.` prefix.
 
 The network (122.4 M parameters: ResNetV2-50 stem + 3 stages with weight-standardised "SAME" convolutions and GroupNorm,
 12 ViT-B blocks on 24 x 24 patch tokens, DPT reassemble / fusion decoder; third-party -- parity unpinned, see
@@ -98,6 +99,8 @@ def random_midas_state_dict(dtype=torch.float16, device="cpu", img: int = 384) -
             out[k] = (0.02 * _fill("midas." + k + ".bias", shp, 1.0) / 0.05).to(device=device, dtype=dtype)
         else:
             out[k] = _fill("midas." + k, shp, 1.0).to(device=device, dtype=dtype)
+    # the head ends in ReLU(conv1x1): with zero-mean random weights 4/5 of the synthetic depth map would be clipped to 0
+    out["scratch.output_conv.4.bias"] = out["scratch.output_conv.4.bias"] + 6.0
     return out
 
 
@@ -116,6 +119,8 @@ class HipMidas:
         self.dtype = torch.float16
         self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()
         spec = midas_param_spec(img)
+        if all(k.startswith("model.") for k in state_dict):           # MidasDetector.state_dict(): the wrapper's attribute name
+            state_dict = {k[len("model."):]: v for k, v in state_dict.items()}
         missing = [k for k in spec if k not in state_dict]
         if missing:
             raise KeyError(f"DPT-Hybrid state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")

@@ -1,10 +1,11 @@
 """ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 CPU restatement (plain PyTorch, fp32) of the depth detector the reference runs once per frame (SURVEY.md section 8f row
-F2): `torch.hub.load("lewiji/MiDaS", "DPT_Hybrid")` (live2diff/animatediff/models/depth_utils.py:11-32), called from
-pipeline_stream_animation_depth.py:553-558 on a 384x384 image batch and returning inverse depth `[B, 384, 384]`.
+F2): `MidasDetector` = `DPTDepthModel(backbone="vitb_rn50_384", non_negative=True)` (live2diff/animatediff/models/
+depth_utils.py:11-32), called from pipeline_stream_animation_depth.py:563 on a 384x384 image batch and returning inverse
+depth `[B, 384, 384]`.
 
-**Parity unpinned.**  The MiDaS repository (un-vendored torch.hub dependency, commit unknown) and the `timm` backbone it builds
+**Parity unpinned.**  The MiDaS repository (un-vendored git submodule `live2diff/MiDaS`, commit unknown) and the `timm` backbone it builds
 on (`vit_base_resnet50_384`) are neither under /root/reference nor installed here, and the reference holds no test vector
 for them.  What is restated is the published DPT-Hybrid architecture (Ranftl et al., "Vision Transformers for Dense
 Prediction", MiDaS v3 `DPTDepthModel(backbone="vitb_rn50_384", non_negative=True)`):
@@ -101,6 +102,21 @@ def midas_param_spec(img: int = 384) -> "OrderedDict[str, Tuple[int, ...]]":
 
 
 # ----------------------------------------------------------------------------- building blocks
+_ROUND = [lambda t: t]
+
+
+class fp16_activations:
+    """Context manager: round the output of every convolution and GroupNorm of the backbone to fp16 (storage emulation of
+    an op-by-op fp16 graph, which is how the reference runs the detector).  Tests use the distance between this and the
+    fp32 forward as the noise floor that an fp16 implementation is allowed."""
+
+    def __enter__(self):
+        _ROUND.append(lambda t: t.half().float())
+
+    def __exit__(self, *a):
+        _ROUND.pop()
+
+
 def same_pad(n: int, k: int, s: int) -> Tuple[int, int]:
     """TF-"SAME" padding of one axis (timm `pad_same`): total = max((ceil(n/s) - 1) * s + k - n, 0), low = total // 2."""
     total = max((math.ceil(n / s) - 1) * s + k - n, 0)
@@ -116,11 +132,11 @@ def std_conv_same(x, w, stride=1, eps=1e-8):
     k = w.shape[-1]
     pt, pb = same_pad(x.shape[-2], k, stride)
     pl, pr = same_pad(x.shape[-1], k, stride)
-    return F.conv2d(F.pad(x, (pl, pr, pt, pb)), ws, None, stride=stride)
+    return _ROUND[-1](F.conv2d(F.pad(x, (pl, pr, pt, pb)), ws, None, stride=stride))
 
 
 def gn(x, sd, p, relu=True):
-    y = F.group_norm(x, GN_GROUPS, sd[p + "weight"].float(), sd[p + "bias"].float(), 1e-5)
+    y = _ROUND[-1](F.group_norm(x, GN_GROUPS, sd[p + "weight"].float(), sd[p + "bias"].float(), 1e-5))
     return F.relu(y) if relu else y
 
 

@@ -28,7 +28,7 @@ def test_integration_md_snippets_run(dry_run, monkeypatch):
     import live2diff_amd.config as C
     from live2diff_amd.weights import unet_param_spec
     blocks = _blocks()
-    assert len(blocks) >= 3, "INTEGRATION.md lost its executable blocks"
+    assert len(blocks) >= 4, "INTEGRATION.md lost its executable blocks"
     ns = {}
     for b in blocks:
         exec(compile(b, "INTEGRATION.md", "exec"), ns)
@@ -68,3 +68,10 @@ def test_integration_md_snippets_run(dry_run, monkeypatch):
     assert stream.vae is vae and vae.config.scaling_factor == 1.0 and vae.dtype == torch.float16
     assert vae.encode(torch.zeros(1, 3, 128, 128, dtype=torch.float16)).latents.shape == (1, 4, 16, 16)
     assert vae.decode(torch.zeros(1, 4, 16, 16, dtype=torch.float16), return_dict=False)[0].shape == (1, 3, 128, 128)
+    # the depth-detector slot: MidasDetector.state_dict() carries the wrapper's `model.` prefix
+    from live2diff_amd.midas_hip import midas_param_spec
+    dsd = {"model." + k: torch.zeros(shp, dtype=torch.float16) for k, shp in midas_param_spec().items()}
+    stream.depth_detector = SimpleNamespace(state_dict=lambda: dsd)
+    det = ns["install_hip_depth"](stream, "cpu")
+    assert stream.depth_detector is det and det.dtype == torch.float16
+    assert det(torch.zeros(1, 3, 384, 384, dtype=torch.float16)).shape == (1, 384, 384)
