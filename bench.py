@@ -147,7 +147,7 @@ def dump_plan(unet, path):
         for j in range(len(st.pl)):
             op = st.pl[j]
             fl, by = op_work(op, _lib)
-            nd = 0 if op.kind == _lib.OP_COPY else (2 if op.kind == _lib.OP_IGEMM and op.i[21] > 1 else 1)
+            nd = 0 if op.kind == _lib.OP_COPY else (2 if op.kind == _lib.OP_IGEMM and op.i[21] > 1 and not op.p[11] else 1)
             f.write(f"{j},{KIND_NAMES.get(op.kind, op.kind)},{op_dims(op, _lib)},{fl:.0f},{by:.0f},{nd}\n")
 
 

@@ -54,7 +54,12 @@ enum {
  *   i12 ups(0|1) i13 M i14 Nout i15 ldo i16 ldr i17 ldrb i18 rows_per_bias i19 epi (0 none, 1 GEGLU, 2 SiLU)
  *   i20 batch (grid.z) ; l0..l3 = per-batch element strides of x1, w, out, residual
  *   p7 16-byte zero page (padding source)   p8 split-K workspace [batch][S][M][round_up(Nout,4)] float
- *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch) i22 tile (0 auto, 1 = 128x128,
+ *   i21 splitk (S, 1 = off: S > 1 adds the igemm_splitk_epilogue launch unless p11 is set)
+ *   p11 (split-K only) int32 arrival counters, one per (batch, tile), ZERO before the launch and left zero by it: the
+ *   reduction is fused -- the block that arrives last at a tile's counter sums the S partial tiles in the fixed order
+ *   0..S-1 and runs the epilogue; p8 is then [batch][tile][S][tile_n * tile_m] float (whole tiles) and i22's tile must be
+ *   explicit (1 or 2).  Results are bit-identical between runs (the order of the sum does not depend on the arrival order).
+ *   i22 tile (0 auto, 1 = 128x128,
  *   2 = 64x64; + 16 = weight-tile-major block order: each XCD's L2 holds a band of output channels, for
  *   GroupNorm statistics of the OUTPUT, accumulated by the producer (replaces the consumer's L2D_OP_GN_STATS launch):
  *   p9 / p10 accumulators int64 [samples][G][2] of up to two consumer GroupNorms, or 0 ; i24 T (tokens per sample)

@@ -29,7 +29,8 @@
 //     the per-stage part (tap offset, channel offset) is wave-uniform scalar work.  Nearest-upsample convs and
 //     3x3 convs over a two-input concat use the generic (slower) gather.
 //   * Split-K (grid.y) for the low-resolution levels (M = 128..2048, K up to 23 040): fp32 partial tiles to a
-//     workspace, reduced in a fixed order by `igemm_splitk_epilogue`, which applies the same fused epilogue.
+//     workspace; the block that arrives last at the tile's counter reduces them in a fixed order and runs the fused
+//     epilogue (round 2; the separate `igemm_splitk_epilogue` launch of round 1 remains as the A/B path, cnt = 0).
 //   * XCD-aware block order: each XCD runs a contiguous tile range, token-tile major or (op.i[22] & 16) weight-tile
 //     major, whichever keeps the larger operand in ONE L2 (28.5 vs 43.6 MB of L2 fills per launch, frame average).
 //   * In-kernel timestamps (s_memtime) on the GEGLU GEMM M 8192 x N 2560 x K 320: a 128x128 block lives 25.8 k cycles,
@@ -38,6 +39,7 @@
 //     the MFMA loop.
 #include "common.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
@@ -47,7 +49,8 @@ struct IGemmArgs {
     const h16 *res;
     h16 *out;
     const h16 *zero;   // >= 16 bytes of zeros
-    float *ws;         // split-K workspace [S][M][NoutP] fp32
+    float *ws;         // split-K workspace fp32: [S][M][NoutP] (two-launch reduction) or [tile][S][TN*TM] (fused, cnt != 0)
+    unsigned int *cnt; // fused split-K reduction: one arrival counter per (batch, tile), zero before and after every launch
     int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
     int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order, epl;
     // GroupNorm statistics of the output for up to two consumer GroupNorms (0 = none): fixed-point int64 accumulators
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     // DMA in the in-order VMEM queue: the loop's counted waits cover them), not after the K loop where each would be one
     // more dependent (cold) round trip on the block's critical path.
     const int NoutO = (a.epi == 1) ? (a.Nout >> 1) : a.Nout;            // GEGLU halves the output width
-    const bool vec = a.epl && gridDim.y == 1 && ((a.ldo | NoutO) & 7) == 0 && (((unsigned long long)outp) & 15) == 0 &&
+    const bool split = gridDim.y > 1;
+    const bool vec = a.epl && (!split || a.cnt) && ((a.ldo | NoutO) & 7) == 0 && (((unsigned long long)outp) & 15) == 0 &&
                      (!resp || ((a.ldr & 7) == 0 && (((unsigned long long)resp) & 15) == 0));
     constexpr bool RES_EARLY = (TN * TM <= 64 * 64);   // 8 + 8 VGPRs; the 128x128 tile would need 32 + 16 across the loop and
                                                        // drop from 3 to 2 blocks per CU: it loads them when the loop ends
@@ -333,17 +337,18 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             biasv[i] = b;
         }
     };
-    if (vec && RES_EARLY) {
+    auto load_early = [&]() {
         load_bias();
         if (resp) {
 #pragma unroll
             for (int it = 0; it < EPI_IT; ++it) {
                 const int c = it * 256 + tid, row = c / CPRN, cc = c % CPRN;
                 const int m = m0 + row, n = n0 + cc * 8;
-                resv[it] = (m < a.M && n < a.Nout) ? l2d_ld8(resp + (long long)m * a.ldr + n) : l2d_zero8();
+                resv[RES_EARLY ? it : 0] = (m < a.M && n < a.Nout) ? l2d_ld8(resp + (long long)m * a.ldr + n) : l2d_zero8();
             }
         }
-    }
+    };
+    if (vec && RES_EARLY && !split) load_early();   // (a split launch fetches them in the one block that runs the epilogue)
     if (kb < ke) issue_x();
 
     f32x4 acc[NI][MI];
@@ -406,8 +411,50 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     }
 
     // ---------------------------------------------------------------- epilogue
-    if (gridDim.y > 1) {
-        // split-K: raw fp32 partial tile; the fused epilogue runs in igemm_splitk_epilogue
+    if (split && a.cnt) {
+        // split-K with the reduction fused into this launch: every block parks its fp32 partial tile in the workspace
+        // (tile-private slab, lane-linear: 16 bytes per lane, read back by the same thread positions), then announces itself
+        // on the tile's arrival counter; the block that arrives LAST sums the S partials in the fixed order 0..S-1 -- its own
+        // included, so the result does not depend on who was last: bit-repeatable -- and runs the normal fused epilogue
+        // (bias / activation / residual / GroupNorm statistics).  No second launch, no second pass over the output.
+        // Cross-XCD visibility WITHOUT cache-wide fences: the partials are written and read with agent-scope (sc1) buffer
+        // accesses -- write-through stores, coherent loads -- and ordered against the arrival atomic by s_waitcnt + the block
+        // barrier.  (__threadfence() here = buffer_wbl2 + buffer_inv of the whole L2 per block: measured 42 us per launch,
+        // the frame went from 9.9 to 12.1 ms.)
+        const int S = gridDim.y;
+        constexpr int AUX_SC1 = 16;
+        float *slab = a.ws + ((z * nwg + wgid) * S) * (long long)(TN * TM);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, S * TN * TM * 4, 0x00020000);
+        const int mine = ((int)blockIdx.y * (TN * TM) + tid * 4) * 4;          // byte offsets inside the tile's slab
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, mine + (i * MI + j) * 4096, 0, AUX_SC1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's partials have been written through ...
+        __syncthreads();                                    // ... every thread's have
+        unsigned int *flag = reinterpret_cast<unsigned int *>(smem);
+        if (tid == 0) *flag = atomicAdd(a.cnt + (z * nwg + wgid), 1u);
+        __syncthreads();
+        const bool last = (*flag == (unsigned int)(S - 1));
+        __syncthreads();                                    // (smem is reused below)
+        if (!last) return;
+        if (tid == 0) atomicExch(a.cnt + (z * nwg + wgid), 0u);                // ready for the next launch that uses this counter
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < S; ++y) {
+            const int src = (y * (TN * TM) + tid * 4) * 4;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, src + (i * MI + j) * 4096, 0, AUX_SC1));
+        }
+        if (vec && RES_EARLY) load_early();
+    } else if (split) {
+        // split-K, two launches: raw fp32 partial tile; the fused epilogue runs in igemm_splitk_epilogue
         const int NoutP = (a.Nout + 3) & ~3;
         float *wsp = a.ws + ((long long)z * gridDim.y + blockIdx.y) * a.M * NoutP;
 #pragma unroll
@@ -698,6 +745,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     int variant = op->i[23];   // pipeline variant, see launch_p
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.gn1 = (unsigned long long *)op->p[9]; a.gn2 = (unsigned long long *)op->p[10];
+    a.cnt = (unsigned int *)op->p[11];
     a.pad = op->i[30] ? 0 : 1;        // i30 = 1: TF-"SAME" low-side padding 0 (stride-2 convs of the ResNetV2 backbone)
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
@@ -707,18 +755,19 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
         (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
-        a.epi < 0 || a.epi > 5 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
+        (a.cnt && a.splitk > 1 && tile == 0) || a.epi < 0 || a.epi > 5 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 10 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
                       op->tag, a.taps, a.C1, a.C2, a.CinP, a.M, a.Nout, a.ldo, a.splitk, tile, (const void *)a.zero);
         return L2D_EINVAL;
     }
     if (a.gn1) {
-        const int tm = (a.splitk > 1 || tile == 2) ? 64 : 128;     // (tile 0 = auto is resolved below: require the larger one)
+        // (tile 0 = auto is resolved below: require the larger one; the two-launch split-K reduction works on 64x64 tiles)
+        const int tm = ((a.splitk > 1 && !a.cnt) || tile == 2) ? 64 : 128;
         const bool vec_ok = a.epl && (a.Nout % 8) == 0 && (a.ldo % 8) == 0 && !(a.res && (a.ldr % 8)) && a.epi != 1;
         if (a.gnT <= 0 || a.gnG <= 0 || a.gnG > 32 || a.cpg1 <= 0 || (a.gn2 && a.cpg2 <= 0) || batch != 1 ||
             ((a.cpg1 | a.choff1) & 1) || (a.gn2 && ((a.cpg2 | a.choff2) & 1)) ||
-            (a.gnT % tm) != 0 || (a.splitk == 1 && !vec_ok) || (a.M % a.gnT) != 0) {
+            (a.gnT % tm) != 0 || ((a.splitk == 1 || a.cnt) && !vec_ok) || (a.M % a.gnT) != 0) {
             l2d_set_error("igemm(tag %d): GroupNorm statistics need T %% tile == 0 (T=%d tile=%d), the LDS-staged epilogue or "
                           "split-K, batch 1 and G <= 32", op->tag, a.gnT, tm);
             return L2D_EINVAL;
@@ -739,7 +788,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         return lrc;
     }
     int rc = l2d_check_launch("igemm", op->tag);
-    if (rc != L2D_OK || a.splitk == 1) return rc;
+    if (rc != L2D_OK || a.splitk == 1 || a.cnt) return rc;
     const int NoutP = (a.Nout + 3) & ~3;
     const unsigned tiles = (unsigned)(((NoutP + 63) / 64) * ((a.M + 63) / 64));
     hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(tiles, 1, batch), dim3(256), 0, s, a, a.splitk);

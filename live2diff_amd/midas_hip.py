@@ -200,6 +200,7 @@ class HipMidas:
         st.inp = torch.zeros(B, 3, H, W_, dtype=torch.float16, device=dev)
         st.gn_acc = torch.zeros(64, B, G, 2, dtype=torch.int64, device=dev)
         st.gn_zero = torch.zeros_like(st.gn_acc)
+        st.sk_cnt, st.sk_used = torch.zeros(1 << 14, dtype=torch.int32, device=dev), 0      # split-K arrival counters (igemm.hip)
         zero_op = pl.append(*ops.copy(st.gn_zero, st.gn_acc, st.gn_acc.numel() * 8))
         add = lambda opk: pl.append(*opk)
         st.taps = {}
@@ -217,8 +218,13 @@ class HipMidas:
                 variant = 1
             if tile == 1 and variant in (7, 8, 9):
                 variant = 5
-            ws = ar.alloc(kw.get("batch", 1) * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
-            op = add(ops.igemm(x, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **kw))
+            ws, cnt_kw = None, {}
+            if S > 1:
+                n_ws, n_cnt = ops.splitk_sizes(kw["M"], kw["Nout"], S, kw.get("batch", 1), tile)
+                ws = ar.alloc(n_ws, torch.float32)
+                cnt_kw = dict(cnt=st.sk_cnt, cnt_off=st.sk_used)
+                st.sk_used += n_cnt
+            op = add(ops.igemm(x, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **cnt_kw, **kw))
             ar.release(ws)
             return op
 

@@ -84,11 +84,12 @@ def igemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -
     (concatenated) channel axis.  Returns False when both slots are taken or the launch cannot do it (include/l2d.h)."""
     assert op.kind == _lib.OP_IGEMM
     splitk, tile = max(1, op.i[21]), op.i[22] & 15
-    tm = 64 if (splitk > 1 or tile == 2) else 128
+    fused = bool(op.p[11])
+    tm = 64 if ((splitk > 1 and not fused) or tile == 2) else 128
     Nout, ldo, ldr, epi, batch = op.i[14], op.i[15], op.i[16], op.i[19], max(1, op.i[20])
     direct = (op.i[22] >> 5) & 1
     vec_ok = (not direct) and Nout % 8 == 0 and ldo % 8 == 0 and not (op.p[5] and ldr % 8) and epi != 1
-    if T % tm or batch != 1 or (splitk == 1 and not vec_ok) or op.i[13] % T or G > 32:
+    if T % tm or batch != 1 or ((splitk == 1 or fused) and not vec_ok) or op.i[13] % T or G > 32:
         return False
     if op.p[9] and (op.i[24], op.i[25]) != (T, G):
         return False
@@ -157,9 +158,11 @@ _TUNED = _load_tuned()
 def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, Hin=1, Win=1, Hout=1, Wout=1, stride=1, ups=0, epi=0,
           batch=1, sx1=0, sw=0, so=0, sres=0, x1_off=0, w_off=0, out_off=0, res_off=0, splitk=1, tile=0, ws=None,
-          variant=5, order=0, pad_same=False):
+          variant=5, order=0, pad_same=False, cnt=None, cnt_off=0):
     """Offsets (in elements) allow sub-views of fp16 buffers without creating tensors.
-    splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements."""
+    splitk > 1 needs `ws`: fp32 workspace of batch * splitk * M * round_up(Nout, 4) elements (two-launch reduction), or, with
+    `cnt` (int32 arrival counters, zero; this launch uses splitk_sizes(...)[1] of them from cnt_off), the fused reduction's
+    splitk_sizes(...)[0] elements: the last-arriving block of a tile reduces and runs the epilogue, no second launch."""
     op = L2dOp()
     op.kind = _lib.OP_IGEMM
     es = 2
@@ -177,7 +180,12 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
         assert bias.dtype == torch.float32
     if rowbias is not None:
         assert rowbias.dtype == torch.float32
-    if splitk > 1:
+    if splitk > 1 and cnt is not None:
+        need_ws, need_cnt = splitk_sizes(M, Nout, splitk, batch, tile)
+        assert tile in (1, 2) and ws is not None and ws.dtype == torch.float32 and ws.numel() >= need_ws
+        assert cnt.dtype == torch.int32 and cnt.numel() >= cnt_off + need_cnt
+        op.p[11] = _ptr(cnt) + 4 * cnt_off
+    elif splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
     direct_epi = 32 if os.environ.get("L2D_IGEMM_EPI", "1") == "0" else 0     # A/B knob: register -> global epilogue
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
@@ -186,7 +194,17 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
         op.i[j] = int(v)
     op.l[0], op.l[1], op.l[2], op.l[3] = int(sx1), int(sw), int(so), int(sres)
     op.i[30] = 1 if pad_same else 0       # TF-"SAME" low-side padding 0 (stride-2 3x3 convs of the ResNetV2 backbone)
-    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt)
+
+
+def splitk_sizes(M: int, Nout: int, splitk: int, batch: int, tile: int):
+    """(fp32 workspace elements, int32 counters) of a split-K igemm with the fused reduction: whole tiles, one slab per split."""
+    t = 128 if tile == 1 else 64
+    ntiles = ((M + t - 1) // t) * ((Nout + t - 1) // t)
+    return batch * ntiles * splitk * t * t, batch * ntiles
+
+
+SPLITK_FUSED = os.environ.get("L2D_IGEMM_SPLITK_FUSED", "1") != "0"     # A/B knob: 0 = separate reduction launch (round 1)
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):

@@ -338,14 +338,24 @@ class HipStreamingUNet:
                 variant = 5            # deep rings exist for the 64x64 tile only (LDS)
             if epi == 1:
                 S = 1                  # GEGLU pairs value and gate in one block's registers: no split-K
-            ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32) if S > 1 else None
+            ws, cnt_kw = None, {}
+            if S > 1 and ops.SPLITK_FUSED:
+                n_ws, n_cnt = ops.splitk_sizes(kw["M"], kw["Nout"], S, batch, tile)
+                ws = ar.alloc(n_ws, torch.float32)
+                cnt_kw = dict(cnt=st.sk_cnt, cnt_off=st.sk_used)
+                st.sk_used += n_cnt
+            elif S > 1:
+                ws = ar.alloc(batch * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32)
             # XCD tile order: weight-tile major when the weight matrix outweighs the activations (L2 fills, see igemm.hip)
             wbytes = kw["Nout"] * taps * kw["CinP"]
             xbytes = kw["M"] * (kw["C1"] + kw.get("C2", 0))
             order = {"0": 0, "1": 1}.get(os.environ.get("L2D_IGEMM_ORDER", ""), int(wbytes > xbytes))
-            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order, **kw))
+            op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order, **cnt_kw, **kw))
             ar.release(ws)
             return op
+
+        # arrival counters of the split-K launches (fused reduction): zero now, every launch leaves them zero
+        st.sk_cnt, st.sk_used = torch.zeros(1 << 15, dtype=torch.int32, device=dev), 0
 
         # ---- static inputs
         st.in_sample = torch.zeros(B, cfg.in_channels, h * w, dtype=torch.float16, device=dev)

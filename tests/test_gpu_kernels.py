@@ -108,7 +108,10 @@ def test_igemm_swapped_batched(L):
 
 @pytest.mark.parametrize("M,K,N,S,tile", [(128, 2560, 1280, 8, 1), (512, 1280, 320, 4, 2), (2048, 640, 640, 2, 1),
                                           (300, 1024, 70, 5, 2), (128, 11520, 256, 24, 1)])
-def test_igemm_splitk(L, M, K, N, S, tile):
+@pytest.mark.parametrize("fused", [False, True])
+def test_igemm_splitk(L, M, K, N, S, tile, fused):
+    """fused: the last-arriving block of a tile reduces the S partial tiles (fixed order) and runs the epilogue -- one launch;
+    otherwise the separate reduction launch of round 1.  Both must leave the same bits on repeated runs."""
     x = rnd(M, K, seed=1)
     w = rnd(N, K, seed=2, scale=K ** -0.5)
     b = rnd(N, seed=3).float()
@@ -117,14 +120,22 @@ def test_igemm_splitk(L, M, K, N, S, tile):
     wp = L.pack_linear(w.to(DEV))
     ldo = (N + 3) // 4 * 4
     out = torch.zeros(M, ldo, dtype=torch.float16, device=DEV)
-    ws = torch.full((S * M * ldo,), float("nan"), dtype=torch.float32, device=DEV)
+    n_ws, n_cnt = L.splitk_sizes(M, N, S, 1, tile) if fused else (S * M * ldo, 0)
+    ws = torch.full((n_ws,), float("nan"), dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(3 + n_cnt, dtype=torch.int32, device=DEV) if fused else None
     ldr = (N + 2 + 3) // 4 * 4
     rp = torch.zeros(M, ldr, dtype=torch.float16)
     rp[:, :N + 2] = r
-    L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, CinP=wp.shape[1], ldo=ldo, bias=b.to(DEV), res=rp.to(DEV),
-                  ldr=ldr, epi=2, splitk=S, tile=tile, ws=ws))
-    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        out.zero_()
+        L.run(L.igemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, CinP=wp.shape[1], ldo=ldo, bias=b.to(DEV), res=rp.to(DEV),
+                      ldr=ldr, epi=2, splitk=S, tile=tile, ws=ws, cnt=cnt, cnt_off=3))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+        assert cnt is None or int(cnt.abs().sum()) == 0            # every launch leaves its arrival counters at zero
     check(out[:, :N], ref, what=f"splitk {M}x{K}x{N} S{S}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_igemm_schedule_matches_plain(L):
@@ -224,6 +235,8 @@ def test_groupnorm(L, C1, C2, T, silu):
     (2, 1024, 640, 640, 2, 1, 640, 1280),     # 64x64 tile; second consumer sees this tensor as the upper half of a concat
     (2, 256, 1280, 640, 2, 1, 1280, 1920),    # the 640-channel half of a 1280 + 640 concat: cpg 60, a group straddles the inputs
     (2, 64, 2560, 1280, 2, 4, 0, 2560),       # split-K: statistics from the (tiled) split-K epilogue, T = 64
+    (2, 64, 2560, 1280, 2, -4, 0, 2560),      # split-K with the fused reduction (negative = fused): the last block of a tile
+    (2, 256, 5120, 1280, 1, -6, 0, 2560),     # ... 128x128 tiles, T = 256
     (8, 64, 320, 320, 2, 1, 0, 640),          # warm-up batch: 8 samples
 ])
 def test_igemm_groupnorm_statistics_from_the_producer(L, B, T, K, C, tile, splitk, choff2, Ccat):
@@ -238,14 +251,16 @@ def test_igemm_groupnorm_statistics_from_the_producer(L, B, T, K, C, tile, split
     r = rnd(M, C, seed=4)
     wp = L.pack_linear(w.to(DEV))
     out = torch.empty(M, C, dtype=torch.float16, device=DEV)
-    ws = torch.empty(splitk * M * C, dtype=torch.float32, device=DEV) if splitk > 1 else None
+    fused, splitk = splitk < 0, abs(splitk)
+    ws = torch.empty(L.splitk_sizes(M, C, splitk, 1, tile)[0] if fused else splitk * M * C, dtype=torch.float32, device=DEV) if splitk > 1 else None
+    cnt = torch.zeros(L.splitk_sizes(M, C, splitk, 1, tile)[1], dtype=torch.int32, device=DEV) if fused else None
     acc = torch.zeros(2, B, G, 2, dtype=torch.int64, device=DEV)
     cpg1, cpg2 = C // G, Ccat // G
     accs = []
     for rep in range(2):
         acc.zero_()
         op, keep = L.igemm(x.to(DEV), wp, out, M=M, Nout=C, C1=K, ldx1=K, CinP=wp.shape[1], ldo=C, bias=b.to(DEV), res=r.to(DEV), ldr=C,
-                           splitk=splitk, tile=tile, ws=ws, variant=1)
+                           splitk=splitk, tile=tile, ws=ws, variant=1, cnt=cnt)
         assert L.igemm_gn_target(op, acc[0].data_ptr(), T=T, G=G, cpg=cpg1, choff=0)
         assert L.igemm_gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=choff2)
         assert not L.igemm_gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=0)      # both slots taken
