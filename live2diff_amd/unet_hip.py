@@ -355,7 +355,7 @@ class HipStreamingUNet:
             return op
 
         # arrival counters of the split-K launches (fused reduction): zero now, every launch leaves them zero
-        st.sk_cnt, st.sk_used = torch.zeros(1 << 15, dtype=torch.int32, device=dev), 0
+        st.sk_cnt, st.sk_used = torch.zeros(1 << 20, dtype=torch.int32, device=dev), 0
 
         # ---- static inputs
         st.in_sample = torch.zeros(B, cfg.in_channels, h * w, dtype=torch.float16, device=dev)

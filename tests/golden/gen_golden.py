@@ -270,6 +270,61 @@ def gen_unet_rollout():
         json.dump(ref_spec, f, indent=0, sort_keys=True)
 
 
+# ----------------------------------------------------------------------------- 8. prepare() + per-frame __call__ chain
+def gen_pipeline_chain():
+    """StreamAnimateDiffusionDepth.prepare (:171-344, incl. the x0 -> re-noise chain between warm-up passes) followed by six
+    `__call__`s (:625-666: encode_image, encode_depth, predict_x0_batch, decode_image) of the REFERENCE class, run unbound on a
+    fake `self` with the deterministic mocks of tests/pipeline_mocks.py.  Captures outputs, buffers, ring-buffer state and the
+    caches after every step; the RNG contract (global seed 123, generator seed 2) is part of what is pinned."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import pipeline_mocks as M
+    P = ref_loader.load_pipeline_class()
+    cls = P.StreamAnimateDiffusionDepth
+    P.retrieve_latents = M.retrieve_latents
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.Event = M.NoCudaEvent
+    torch.cuda.synchronize = lambda *a, **k: None
+    out = {}
+    for n, t_index in ((2, [30, 40]), (3, [20, 30, 45])):
+        sch = M.MockScheduler()
+        fake = type("S", (), {})()
+        for name in ("prepare", "initialize_attn_bias_pe_and_update_idx", "update_attn_bias", "scheduler_step_batch", "add_noise",
+                     "encode_image", "decode_image", "encode_depth", "predict_x0_batch", "unet_step", "warmup_engine"):
+            setattr(fake, name, getattr(cls, name).__get__(fake))
+        fake.device, fake.dtype = torch.device("cpu"), torch.float32
+        fake.height, fake.width, fake.latent_height, fake.latent_width = M.H, M.W, M.H // 8, M.W // 8
+        fake.denoising_steps_num, fake.frame_bff_size, fake.batch_size = n, 1, n
+        fake.cfg_type, fake.use_denoising_batch, fake.do_add_noise, fake.clip_skip = "none", True, True, 1
+        fake.t_list, fake.scheduler, fake.timesteps = t_index, sch, sch.timesteps
+        fake.pipe, fake.image_processor, fake.vae, fake.depth_detector = M.MockPipe(), M.MockImageProcessor(), M.MockVAE(), M.MockDepth()
+        fake.unet, fake.unet_warmup = M.MockStreamUNet(), M.MockWarmupUNet()
+        fake.kv_cache_list = M.make_caches(n)
+        fake.similar_image_filter, fake.is_tensorrt = False, False
+        fake.inference_time_ema = fake.depth_time_ema = 0
+        fake.inference_time_list, fake.depth_time_list = [], []
+        torch.manual_seed(123)
+        warm = fake.prepare(M.frames(8, seed=7), "a prompt", seed=2)
+        k = f"n{n}_"
+        out[k + "prepare_out"] = warm
+        out[k + "prepare_caches"] = torch.stack(fake.kv_cache_list)
+        out[k + "sub_timesteps"] = fake.sub_timesteps_tensor
+        out[k + "c_skip"], out[k + "c_out"] = fake.c_skip, fake.c_out
+        out[k + "alpha"], out[k + "beta"] = fake.alpha_prod_t_sqrt, fake.beta_prod_t_sqrt
+        out[k + "init_noise"] = fake.init_noise
+        outs, bufs, dbufs = [], [], []
+        for i, img in enumerate(M.frames(6, seed=11)):
+            outs.append(cls.__call__(fake, img))
+            bufs.append(fake.x_t_latent_buffer.clone())
+            dbufs.append(fake.depth_latent_buffer.clone())
+        out[k + "frame_out"] = torch.stack(outs)
+        out[k + "x_t_buffer"], out[k + "depth_buffer"] = torch.stack(bufs), torch.stack(dbufs)
+        out[k + "caches"] = torch.stack(fake.kv_cache_list)
+        out[k + "bias"], out[k + "pe_idx"], out[k + "update_idx"] = fake.attn_bias, fake.pe_idx, fake.update_idx
+        out[k + "unet_t"] = torch.stack([c["t"] for c in fake.unet.log])
+        out[k + "unet_update_idx"] = torch.stack([c["update_idx"] for c in fake.unet.log])
+    save("pipeline_chain", **out)
+
+
 if __name__ == "__main__":
     gen_pe()
     gen_state_machine()
@@ -278,4 +333,5 @@ if __name__ == "__main__":
     gen_resnet_family()
     gen_spatial()
     gen_unet_rollout()
+    gen_pipeline_chain()
     print("done")

@@ -312,3 +312,46 @@ def test_pipeline_mirror_keeps_the_reference_api_surface():
     assert out.shape == (1, 4, 1, 4, 4) and torch.allclose(out, torch.full_like(out, x0), atol=1e-6)
     assert torch.allclose(s.x_t_latent_buffer, torch.full((1, 4, 1, 4, 4), 0.8 * x0), atol=1e-6)
     assert s.update_idx.tolist() == [9, 8]                             # frame 1 of the reference trace (row 1 lags row 0 by a slot)
+
+
+@pytest.mark.parametrize("n,t_index", [(2, [30, 40]), (3, [20, 30, 45])])
+def test_prepare_and_call_chain_match_reference_capture(golden, monkeypatch, n, t_index):
+    """A12 + the per-frame glue, pinned to the REFERENCE: tests/golden/pipeline_chain.npz holds prepare() (warm-up passes with the
+    x0 -> re-noise chain between them, reference :171-344) and six `__call__`s (:625-666) of the reference's
+    StreamAnimateDiffusionDepth run on deterministic mock models (tests/pipeline_mocks.py).  The mirror, driven with the same
+    mocks, seeds and inputs, must reproduce outputs, latent / depth shift registers, ring-buffer state, every cache and the
+    sequence of UNet arguments -- which also pins the order and shapes of the random draws (global RNG + `generator`)."""
+    import pipeline_mocks as M
+    from live2diff_amd import pipeline_stream_animation_depth as P
+    g = golden("pipeline_chain")
+    k = f"n{n}_"
+    monkeypatch.setattr(torch.cuda, "Event", M.NoCudaEvent)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **kw: None)
+    monkeypatch.setattr(P, "retrieve_latents", M.retrieve_latents)
+    pipe = M.MockPipe()
+    pipe.unet, pipe.vae, pipe.depth_model = M.MockStreamUNet(), M.MockVAE(), M.MockDepth()
+    s = P.StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=t_index, torch_dtype=torch.float32, width=M.W, height=M.H)
+    s.scheduler = M.MockScheduler()
+    s.timesteps = s.scheduler.timesteps
+    s.image_processor = M.MockImageProcessor()
+    s.unet_warmup = M.MockWarmupUNet()
+    s.kv_cache_list = M.make_caches(n)
+    torch.manual_seed(123)
+    warm = s.prepare(M.frames(8, seed=7), "a prompt", seed=2)
+    T = lambda name: torch.from_numpy(g[k + name])
+    close = lambda a, b: torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(s.sub_timesteps_tensor, T("sub_timesteps"))
+    for mine, name in ((s.c_skip, "c_skip"), (s.c_out, "c_out"), (s.alpha_prod_t_sqrt, "alpha"), (s.beta_prod_t_sqrt, "beta")):
+        assert close(mine, T(name)), name
+    assert torch.equal(s.init_noise, T("init_noise"))                     # same draw from the same RNG stream
+    assert close(warm, T("prepare_out"))
+    assert close(torch.stack(s.kv_cache_list), T("prepare_caches"))
+    for i, img in enumerate(M.frames(6, seed=11)):
+        out = s(img)
+        assert close(out, T("frame_out")[i]), f"frame {i}"
+        assert close(s.x_t_latent_buffer, T("x_t_buffer")[i]) and close(s.depth_latent_buffer, T("depth_buffer")[i]), f"buffers {i}"
+    assert close(torch.stack(s.kv_cache_list), T("caches"))
+    assert torch.equal(torch.isinf(s.attn_bias), torch.isinf(T("bias"))) and torch.equal(s.pe_idx, T("pe_idx"))
+    assert torch.equal(s.update_idx, T("update_idx"))
+    assert torch.equal(torch.stack([c["t"] for c in pipe.unet.log]), T("unet_t"))
+    assert torch.equal(torch.stack([c["update_idx"] for c in pipe.unet.log]), T("unet_update_idx"))
