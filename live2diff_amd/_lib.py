@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- MUST precede loading libl2d_hip.so: the extension
 #                      already loaded (one runtime per process: shared streams and device pointers)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libl2d_hip.so")
+LIB_PATH = os.environ.get("L2D_LIB") or os.path.join(_HERE, "libl2d_hip.so")     # L2D_LIB: analysis builds (make PROBES=1), tools only
 
 # op kinds (include/l2d.h)
 OP_IGEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_FLASH_ATTN = 1, 2, 3, 4, 5

@@ -44,22 +44,57 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 struct IGemmArgs {
-    const h16 *x1, *x2, *w;
+    // Field order = order of first use in the kernel: the argument block is fetched through the scalar cache in 64-byte lines,
+    // every line touched for the first time is one more dependent miss (~500 cycles) on the block's critical path.
+    // -- line 0: what the first weight DMA needs
+    const h16 *w;
+    const h16 *zero;   // >= 16 bytes of zeros
+    long long sw;
+    int Nout, Kp, nwg, ntn, ntm, order, splitk;      // nwg = ntn * ntm = gridDim.x (tiles), splitk = gridDim.y
+    float inv_ntn, inv_ntm, inv_s;                    // reciprocals for the exact float-assisted divisions (l2d_divf)
+    // -- token-row descriptors
+    const h16 *x1, *x2;
+    long long sx1;
+    int M, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, taps;
+    int pad;   // low-side zero padding of the 3x3 gather: 1 (symmetric, nn.Conv2d padding=1) or 0 (TF-"SAME" of a stride-2 conv on an even size)
+    float inv_hw, inv_wout;
+    // -- epilogue
     const float *bias, *rowbias;
     const h16 *res;
     h16 *out;
-    const h16 *zero;   // >= 16 bytes of zeros
+    long long so, sres;
+    int ldo, ldr, ldrb, rows_per_bias, epi, epl;
     float *ws;         // split-K workspace fp32: [S][M][NoutP] (two-launch reduction) or [tile][S][TN*TM] (fused, cnt != 0)
     unsigned int *cnt; // fused split-K reduction: one arrival counter per (batch, tile), zero before and after every launch
-    int taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups;
-    int M, Nout, ldo, ldr, ldrb, rows_per_bias, epi, Kp, splitk, order, epl;
     // GroupNorm statistics of the output for up to two consumer GroupNorms (0 = none): fixed-point int64 accumulators
     // [sample][G][2]; T tokens per sample; (channels per group, channel offset in the consumer's concatenated axis) each
     unsigned long long *gn1, *gn2;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
-    int pad;   // low-side zero padding of the 3x3 gather: 1 (symmetric, nn.Conv2d padding=1) or 0 (TF-"SAME" of a stride-2 conv on an even size)
-    long long sx1, sw, so, sres;
+#ifdef L2D_PROBES
+    unsigned long long *probe;   // analysis builds: 8 s_memtime stamps per block (thread 0), see tools/igemm_probe.py
+#endif
 };
+
+#ifdef L2D_PROBES
+static unsigned long long *g_igemm_probe = nullptr;
+extern "C" void l2d_igemm_set_probe(void *p) { g_igemm_probe = (unsigned long long *)p; }
+#define L2D_STAMP(i)                                                                                              \
+    do {                                                                                                          \
+        if (a.probe && threadIdx.x == 0)                                                                          \
+            a.probe[((blockIdx.z * gridDim.y + blockIdx.y) * (unsigned long long)gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define L2D_STAMP(i) do { } while (0)
+#endif
+
+// n / d for 0 <= n < 2^24, d >= 1, inv = 1.0f / d: float estimate (within one of the quotient) + one correction step either
+// way -- ~8 instructions instead of the ~35 of the compiler's 32-bit division sequence (or ~150 for a 64-bit one)
+__device__ __forceinline__ int l2d_divf(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    const int r = n - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
+}
 
 // sum x in units of 2^-20, sum x^2 in units of 2^-12: integer adds commute, so the accumulated statistics do not depend on
 // the order in which blocks arrive (bit-repeatable frames), and |x| <= 65504 cannot overflow int64 at any size used here
@@ -145,6 +180,19 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     constexpr int STAGE = (TN + TM) * BK;   // halfs
     extern __shared__ __attribute__((aligned(16))) h16 smem[];   // NS * STAGE halfs (the ONLY LDS object)
 
+    // Touch every 64-byte line of the argument block NOW (four throw-away scalar loads, all in flight together): the
+    // compiler fetches arguments where they are first used, which made the path to the first DMA a chain of 4-5 dependent
+    // scalar-cache misses.  The destination registers stay reserved until the `asm("")` below the first DMA issue; the
+    // compiler's own lgkmcnt(0) waits in between cover these loads too (the counter is per wave, not per instruction).
+    unsigned ka0, ka1, ka2, ka3;
+    {
+        const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        static_assert(sizeof(IGemmArgs) > 0xc0 + 4, "argument block shrank: adjust the warm-up offsets");
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                     : "=&s"(ka0), "=&s"(ka1), "=&s"(ka2), "=&s"(ka3)
+                     : "s"(kp));
+    }
+    L2D_STAMP(0);                                       // block entry
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,7 +202,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
 
     // XCD-aware tile order (blocks are dispatched round-robin over the 8 XCDs): bijective remap so that
     // consecutive tiles -- same token tile, neighbouring weight tiles -- share one XCD's L2
-    const int nwg = gridDim.x;
+    const int nwg = a.nwg;             // == gridDim.x (from the argument block: gridDim comes through one more scalar load)
     int wgid;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -164,35 +212,34 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     // all weight tiles: every XCD's L2 pulls the whole weight matrix -- right when activations dominate); order 1:
     // weight-tile major (an XCD owns a band of output channels: the weights enter ONE L2, the small activation
     // matrix enters all eight -- right for the low-resolution levels, where weights are 10-100x the activations).
-    const int ntn = (a.Nout + TN - 1) / TN;
     int tile_n, tile_m;
     if (a.order) {
-        const int ntm = nwg / ntn;
-        tile_m = wgid % ntm;
-        tile_n = wgid / ntm;
+        tile_n = l2d_divf(wgid, a.ntm, a.inv_ntm);
+        tile_m = wgid - tile_n * a.ntm;
     } else {
-        tile_n = wgid % ntn;
-        tile_m = wgid / ntn;
+        tile_m = l2d_divf(wgid, a.ntn, a.inv_ntn);
+        tile_n = wgid - tile_m * a.ntn;
     }
     const int n0 = tile_n * TN, m0 = tile_m * TM;
     const long long z = blockIdx.z;
-    const h16 *x1 = a.x1 + z * a.sx1;
     const h16 *wp = a.w + z * a.sw;
-    h16 *outp = a.out + z * a.so;
-    const h16 *resp = a.res ? a.res + z * a.sres : nullptr;
-    const int Ctot = a.C1 + a.C2;
 
     // split-K: this block owns K steps [kb, ke)
     const int nk = a.Kp / BK;
-    const int kb = (int)(((long long)nk * blockIdx.y) / gridDim.y);
-    const int ke = (int)(((long long)nk * (blockIdx.y + 1)) / gridDim.y);
+    int kb = 0, ke = nk;
+    if (a.splitk > 1) {                // nk * S < 2^24
+        kb = l2d_divf(nk * (int)blockIdx.y, a.splitk, a.inv_s);
+        ke = l2d_divf(nk * ((int)blockIdx.y + 1), a.splitk, a.inv_s);
+    }
 
     // issue_w() / issue_x() are called for consecutive stages kb, kb+1, ...: ring slot, k offset and the conv tap are
     // tracked incrementally (no division / modulo in the loop); everything except the final add/select is wave-uniform
     int is_slot = 0, is_tap = 0, is_cb = kb * BK;
     if (MODE != 0) {
-        is_tap = (kb * BK) / a.CinP;
-        is_cb = kb * BK - is_tap * a.CinP;
+        if (kb > 0) {                  // (split launches only)
+            is_tap = (kb * BK) / a.CinP;
+            is_cb = kb * BK - is_tap * a.CinP;
+        }
     }
 
     // ---- per-lane DMA descriptors.  Within an RPI-row group lane l serves row l/SPR, physical slot l%SPR.
@@ -221,6 +268,12 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     // the token-row descriptors (integer divisions, 9-tap masks) are computed, so that arithmetic runs under the first
     // (cold: the previous kernel's end flushed the L2s) memory round trip instead of in front of it.
     if (kb < ke) issue_w();
+    L2D_STAMP(1);                                       // first weight stage issued
+    asm volatile("" ::"s"(ka0), "s"(ka1), "s"(ka2), "s"(ka3));      // (end of the warm-up registers' reservation)
+    const h16 *x1 = a.x1 + z * a.sx1;
+    h16 *outp = a.out + z * a.so;
+    const h16 *resp = a.res ? a.res + z * a.sres : nullptr;
+    const int Ctot = a.C1 + a.C2;
 
     // token rows: xoff = element offset of (row, channel slot) from x1 for tap (0,0) [MODE 1] / for k = 0 [MODE 0]
     long long xoff[NIX];
@@ -239,8 +292,8 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             xb[j] = m;
         } else {
             const int hw = a.Hout * a.Wout;
-            const int b = m / hw, rr = m - b * hw;
-            const int oy = rr / a.Wout, ox = rr - oy * a.Wout;
+            const int b = l2d_divf(m, hw, a.inv_hw), rr = m - b * hw;      // m < 2^24 (validated)
+            const int oy = l2d_divf(rr, a.Wout, a.inv_wout), ox = rr - oy * a.Wout;
             xb[j] = b; xy[j] = oy; xx[j] = ox;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
             xoff[j] = (((long long)b * a.Hin + iy0) * a.Win + ix0) * a.ldx1 + xls[j];
@@ -307,7 +360,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     // DMA in the in-order VMEM queue: the loop's counted waits cover them), not after the K loop where each would be one
     // more dependent (cold) round trip on the block's critical path.
     const int NoutO = (a.epi == 1) ? (a.Nout >> 1) : a.Nout;            // GEGLU halves the output width
-    const bool split = gridDim.y > 1;
+    const bool split = a.splitk > 1;
     const bool vec = a.epl && (!split || a.cnt) && ((a.ldo | NoutO) & 7) == 0 && (((unsigned long long)outp) & 15) == 0 &&
                      (!resp || ((a.ldr & 7) == 0 && (((unsigned long long)resp) & 15) == 0));
     constexpr bool RES_EARLY = (TN * TM <= 64 * 64);   // 8 + 8 VGPRs; the 128x128 tile would need 32 + 16 across the loop and
@@ -395,11 +448,13 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
 #pragma unroll
     for (int s = 1; s < NS - 1; ++s)
         if (kb + s < ke) issue();
+    L2D_STAMP(2);                                       // descriptors computed, prologue stages issued
     // steady state: stage kt has landed when at most (NS-2) younger stages are still outstanding
     int kt = kb;
     for (; kt + (NS - 1) < ke; ++kt) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();      // every wave's share of stage kt is in LDS; everyone finished stage kt-1
+        if (kt == kb) L2D_STAMP(3);        // first stage landed
         issue();                           // refill the ring slot that stage kt-1 occupied
         compute();
     }
@@ -411,6 +466,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     }
 
     // ---------------------------------------------------------------- epilogue
+    L2D_STAMP(4);                                       // K loop done
     if (split && a.cnt) {
         // split-K with the reduction fused into this launch: every block parks its fp32 partial tile in the workspace
         // (tile-private slab, lane-linear: 16 bytes per lane, read back by the same thread positions), then announces itself
@@ -421,7 +477,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
         // accesses -- write-through stores, coherent loads -- and ordered against the arrival atomic by s_waitcnt + the block
         // barrier.  (__threadfence() here = buffer_wbl2 + buffer_inv of the whole L2 per block: measured 42 us per launch,
         // the frame went from 9.9 to 12.1 ms.)
-        const int S = gridDim.y;
+        const int S = a.splitk;
         constexpr int AUX_SC1 = 16;
         float *slab = a.ws + ((z * nwg + wgid) * S) * (long long)(TN * TM);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, S * TN * TM * 4, 0x00020000);
@@ -456,7 +512,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     } else if (split) {
         // split-K, two launches: raw fp32 partial tile; the fused epilogue runs in igemm_splitk_epilogue
         const int NoutP = (a.Nout + 3) & ~3;
-        float *wsp = a.ws + ((long long)z * gridDim.y + blockIdx.y) * a.M * NoutP;
+        float *wsp = a.ws + ((long long)z * a.splitk + blockIdx.y) * a.M * NoutP;
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int m = m0 + wm * (TM / 2) + j * 16 + li;
@@ -531,6 +587,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
         constexpr int CPRN_LOG = (CPRN == 16) ? 4 : 3;
         const int cshift = (a.epi == 1) ? CPRN_LOG - 1 : CPRN_LOG;      // 16-byte chunks per output row = 1 << cshift
         const int n0o = (a.epi == 1) ? (n0 >> 1) : n0;
+        L2D_STAMP(5);                                   // tile transposed into LDS (issue side)
         h16x8 rlate[RES_EARLY ? 1 : EPI_IT];
         if (!RES_EARLY && resp) {                                       // big tile: residual loads fly during the transpose
 #pragma unroll
@@ -568,6 +625,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
                 }
             }
         }
+        L2D_STAMP(6);                                   // row stores issued
         if (gn) {
             // GroupNorm statistics of what was just stored (the fp16 values the consumer will read): thread -> channel
             // -> group inside the block, then two integer atomics per (consumer, overlapped group).  The plan builder only
@@ -591,6 +649,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             igemm_gn_flush(a.gn1, a.gnG, a.cpg1 >> 1, a.choff1 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
             igemm_gn_flush(a.gn2, a.gnG, a.cpg2 >> 1, a.choff2 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
         }
+        L2D_STAMP(7);                                   // block done (issue side)
         return;
     }
     if (a.epi == 1) {
@@ -696,8 +755,12 @@ static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
             (void)hipGetLastError();
     }
     int ntn = (a.Nout + TN - 1) / TN, ntm = (a.M + TM - 1) / TM;
+    IGemmArgs b = a;
+    b.ntn = ntn; b.ntm = ntm; b.nwg = ntn * ntm;
+    b.inv_ntn = 1.0f / (float)ntn; b.inv_ntm = 1.0f / (float)ntm; b.inv_s = 1.0f / (float)a.splitk;
+    b.inv_hw = 1.0f / (float)(a.Hout * a.Wout > 0 ? a.Hout * a.Wout : 1); b.inv_wout = 1.0f / (float)(a.Wout > 0 ? a.Wout : 1);
     dim3 grid(ntn * ntm, a.splitk, batch), block(256);
-    hipLaunchKernelGGL((igemm_kernel<TN, TM, MODE, BK, NS>), grid, block, LDS, s, a);
+    hipLaunchKernelGGL((igemm_kernel<TN, TM, MODE, BK, NS>), grid, block, LDS, s, b);
 }
 
 // pipeline variants (op.i[23]): 0 = BK32 x 4 stages, 1 = BK64 x 3, 2 = BK64 x 4, 3 = BK32 x 6, 4 = BK32 x 3,
@@ -746,6 +809,9 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     a.sx1 = op->l[0]; a.sw = op->l[1]; a.so = op->l[2]; a.sres = op->l[3];
     a.gn1 = (unsigned long long *)op->p[9]; a.gn2 = (unsigned long long *)op->p[10];
     a.cnt = (unsigned int *)op->p[11];
+#ifdef L2D_PROBES
+    a.probe = g_igemm_probe;
+#endif
     a.pad = op->i[30] ? 0 : 1;        // i30 = 1: TF-"SAME" low-side padding 0 (stride-2 convs of the ResNetV2 backbone)
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
@@ -772,6 +838,10 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
                           "split-K, batch 1 and G <= 32", op->tag, a.gnT, tm);
             return L2D_EINVAL;
         }
+    }
+    if (a.M >= (1 << 24) || (long long)((a.M + 63) / 64) * ((a.Nout + 63) / 64) >= (1 << 24)) {
+        l2d_set_error("igemm(tag %d): M = %d / tile count beyond the 2^24 range of the kernel's index arithmetic", op->tag, a.M);
+        return L2D_EINVAL;
     }
     if (a.taps == 9 && (a.M != a.B * a.Hout * a.Wout)) {
         l2d_set_error("igemm(tag %d): M != B*Hout*Wout", op->tag);

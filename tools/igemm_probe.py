@@ -1,49 +1,90 @@
-#!/usr/bin/env python
-"""Isolated timing of a few igemm shapes over every (tile, pipeline variant): what the tile kernel itself can reach
-on the short-K shapes that dominate the frame (warm L2; HIP events over 20 back-to-back launches)."""
+"""Where does an igemm block spend its life?  Needs the analysis build of the library (in-kernel s_memtime stamps):
+    make -C live2diff_amd/csrc clean && make -C live2diff_amd/csrc PROBES=1 LIB=../libl2d_hip_probes.so && make -C live2diff_amd/csrc clean && make -C live2diff_amd/csrc
+    L2D_LIB=live2diff_amd/libl2d_hip_probes.so python tools/igemm_probe.py
+Per shape: median cycles between the 8 stamps of a block (entry, first weight DMA issued, descriptors + prologue issued, first
+stage landed, K loop done, tile transposed to LDS, row stores issued, done), the spread of block entry times and the kernel's
+HIP-event duration.  Stamps are the shader clock (s_memtime)."""
+import ctypes
+import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import torch  # noqa: E402
+import torch
 
-from live2diff_amd import _lib, ops  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from live2diff_amd import _lib, ops                                             # noqa: E402
 
 DEV = "cuda"
-SHAPES = [  # M, N, K, epi
-    (8192, 2560, 320, 1), (2048, 5120, 640, 1), (512, 10240, 1280, 1), (8192, 960, 320, 0), (8192, 320, 320, 0),
-    (2048, 640, 640, 0), (512, 1280, 1280, 0), (8192, 320, 1280, 0),
+SHAPES = [  # (name, taps, M, N, K(Cin), tile, S, variant, epi, res)
+    ("CxC level0", 1, 8192, 320, 320, 2, 1, 1, 0, True),
+    ("CxC level1", 1, 2048, 640, 640, 2, 1, 1, 0, True),
+    ("CxC level2", 1, 512, 1280, 1280, 2, 1, 7, 0, True),
+    ("CxC level3", 1, 128, 1280, 1280, 2, 3, 1, 0, True),
+    ("tiny conv", 9, 8192, 16, 64, 2, 1, 9, 2, False),
+    ("GEGLU l0", 1, 8192, 2560, 320, 1, 1, 4, 1, False),
+    ("GEGLU l1", 1, 2048, 5120, 640, 1, 1, 10, 1, False),
+    ("conv l0", 9, 8192, 320, 320, 2, 1, 1, 0, True),
+    ("ff2 l0", 1, 8192, 320, 1280, 2, 1, 5, 0, True),
 ]
 
 
 def main():
+    _lib.lib.l2d_igemm_set_probe.argtypes = [ctypes.c_void_p]
     g = torch.Generator(device=DEV).manual_seed(0)
-    rn = lambda *s: torch.randn(*s, generator=g, device=DEV, dtype=torch.float16)
-    for M, N, K, epi in SHAPES:
-        x = rn(M, K)
-        if epi == 1:
-            w, b = ops.pack_geglu(rn(N, K) * K ** -0.5, torch.zeros(N, device=DEV))
-            out = torch.empty(M, N // 2, dtype=torch.float16, device=DEV)
-            ldo = N // 2
-        else:
-            w, b = ops.pack_linear(rn(N, K) * K ** -0.5), torch.zeros(N, device=DEV)
-            out = torch.empty(M, N, dtype=torch.float16, device=DEV)
-            ldo = N
-        res = []
-        for tile in (1, 2):
-            for v in range(10):
-                if (v in (6, 7) and K % 128) or (tile == 1 and v in (7, 8, 9)):
-                    continue
-                op, keep = ops.igemm(x, w, out, M=M, Nout=N, C1=K, ldx1=K, CinP=w.shape[1], ldo=ldo, bias=b, epi=epi, tile=tile, variant=v)
-                pl = _lib.OpList()
-                pl.append(op, *keep)
-                pl.time_ms(3)
-                us = 1e3 * pl.time_ms(20)
-                res.append((us, tile, v))
-        res.sort()
-        fl = 2.0 * M * N * K
-        print(f"M{M} N{N} K{K} e{epi}: " + "  ".join(f"t{t}v{v} {us:.1f}us({fl / us / 1e6:.0f}TF)" for us, t, v in res[:6]), flush=True)
+    res_all = {}
+    for name, taps, M, N, K, tile, S, variant, epi, use_res in SHAPES:
+        cinp = ops.round_up(K, 64)
+        x = torch.randn(M, K, device=DEV, generator=g).half()
+        w = (torch.randn(N, taps * cinp, device=DEV, generator=g) * (taps * K) ** -0.5).half()
+        b = torch.randn(N, device=DEV, generator=g)
+        No = N // 2 if epi == 1 else N
+        ldo = max(4, No)
+        out = torch.zeros(M, ldo, device=DEV, dtype=torch.float16)
+        res = torch.randn(M, No, device=DEV, generator=g).half() if use_res else None
+        kw = dict(M=M, Nout=N, C1=K, ldx1=K, CinP=cinp, ldo=ldo, bias=b, epi=epi, res=res, ldr=(No if use_res else 0), taps=taps, tile=tile,
+                  variant=variant, splitk=S)
+        if taps == 9:
+            kw.update(B=2, Hin=64, Win=64, Hout=64, Wout=64)
+        if S > 1:
+            n_ws, n_cnt = ops.splitk_sizes(M, N, S, 1, tile)
+            kw.update(ws=torch.zeros(n_ws, device=DEV), cnt=torch.zeros(n_cnt, dtype=torch.int32, device=DEV))
+        op = ops.igemm(x, w, out, **kw)
+        t = 128 if tile == 1 else 64
+        nblk = ((M + t - 1) // t) * ((N + t - 1) // t) * S
+        probe = torch.zeros(nblk * 8, dtype=torch.int64, device=DEV)
+        pl = _lib.OpList()
+        pl.append(*op)
+        for _ in range(3):
+            pl.run()
+        torch.cuda.synchronize()
+        ms = pl.time_ms(reps=20)
+        _lib.lib.l2d_igemm_set_probe(ctypes.c_void_p(probe.data_ptr()))
+        pl.run()
+        torch.cuda.synchronize()
+        _lib.lib.l2d_igemm_set_probe(None)
+        p = probe.view(nblk, 8).cpu()
+        p = p[(p > 0).all(1)]                                  # (split-K: only the reducing block of a tile reaches stamps 5-7)
+        names = ["w_issue", "desc+prologue", "first_stage_wait", "k_loop", "to_lds", "stores", "gn+end"]
+        # the counter is per XCD (not synchronised across XCDs): order blocks by entry time within their own clock domain
+        # (domains show up as clusters > 1e9 apart) and report early / late blocks of the largest cluster separately
+        order = p[:, 0].argsort()
+        p = p[order]
+        gaps = (p[1:, 0] - p[:-1, 0]) > 10_000_000
+        cl = torch.cat([torch.zeros(1, dtype=torch.long), gaps.long().cumsum(0)])
+        big = cl.bincount().argmax()
+        q = p[cl == big]
+        d = (q[:, 1:] - q[:, :-1]).float()
+        k = max(1, q.shape[0] // 3)
+        entry = (q[:, 0] - q[0, 0]).float()
+        row = dict(us=round(ms * 1e3, 2), blocks=int(p.shape[0]), clusters=int(cl.max()) + 1, in_cluster=int(q.shape[0]),
+                   phases_med=dict(zip(names, [int(v) for v in d.median(0).values])),
+                   phases_first_third=dict(zip(names, [int(v) for v in d[:k].median(0).values])),
+                   phases_last_third=dict(zip(names, [int(v) for v in d[-k:].median(0).values])),
+                   entry_first_third=int(entry[:k].median()), entry_last_third=int(entry[-k:].median()),
+                   life_med=int((q[:, 7] - q[:, 0]).float().median()), span=int(q[:, 7].max() - q[0, 0]))
+        res_all[name] = row
+        print(name, json.dumps(row))
+    return res_all
 
 
 if __name__ == "__main__":
