@@ -368,14 +368,17 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     constexpr int CPRN = TN / 8;                                        // 16-byte chunks per output row (non-GEGLU)
     constexpr int EPI_IT = (TM * CPRN) / 256;
     f32x4 biasv[NI];
+    f32x4 rbv[RES_EARLY ? NI : 1];     // 64x64 tile: the row bias stays in its own registers until the epilogue -- adding it
+                                       // here would make the prologue wait (vmcnt 0) for both loads behind the first DMA
     h16x8 resv[RES_EARLY ? EPI_IT : 1];
     bool rb_in_bias = false;
     auto load_bias = [&]() {
         const float *rbp = nullptr;
         if (a.rowbias) {
             const int mlast = (m0 + TM <= a.M ? m0 + TM : a.M) - 1;
-            if (m0 / a.rows_per_bias == mlast / a.rows_per_bias) {      // the whole tile lies in one sample
-                rbp = a.rowbias + (long long)(m0 / a.rows_per_bias) * a.ldrb;
+            const int smp = l2d_divf(m0, a.rows_per_bias, 1.0f / (float)a.rows_per_bias);
+            if (mlast < (smp + 1) * a.rows_per_bias) {                  // the whole tile lies in one sample
+                rbp = a.rowbias + (long long)smp * a.ldrb;
                 rb_in_bias = true;
             }
         }
@@ -385,8 +388,12 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (n < a.Nout) {
                 if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + n);
-                if (rbp) b += *reinterpret_cast<const f32x4 *>(rbp + n);
+                if (rbp) {
+                    if constexpr (RES_EARLY) rbv[i] = *reinterpret_cast<const f32x4 *>(rbp + n);
+                    else b += *reinterpret_cast<const f32x4 *>(rbp + n);
+                }
             }
+            if constexpr (RES_EARLY) { if (!rbp || n >= a.Nout) rbv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
             biasv[i] = b;
         }
     };
@@ -564,6 +571,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
                 for (int i = 0; i < NI; ++i) {
                     const int col = wn * (TN / 2) + i * 16 + lg * 4;
                     f32x4 v = acc[i][j] + biasv[i];
+                    if constexpr (RES_EARLY) v += rbv[i];
                     if (rb && n0 + col < a.Nout) v += *reinterpret_cast<const f32x4 *>(rb + n0 + col);
                     if (a.epi == 2) {
 #pragma unroll
@@ -820,7 +828,7 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
         a.M <= 0 || a.Nout <= 0 || (a.C1 % 8) || (a.C2 % 8) || (a.C2 > 0 && !a.x2) || a.C1 + a.C2 > a.CinP ||
         (a.ldo % 4) || (a.ldx1 % 8) || (a.C2 > 0 && (a.ldx2 % 8)) ||
         (a.res && (a.ldr % 4)) || (a.rowbias && a.rows_per_bias <= 0) ||
-        (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res)) || (a.stride != 1 && a.stride != 2) ||
+        (a.epi == 1 && (!a.bias || (a.Nout % 32) || a.splitk != 1 || a.res || a.rowbias)) || (a.stride != 1 && a.stride != 2) ||
         (a.cnt && a.splitk > 1 && tile == 0) || a.epi < 0 || a.epi > 5 || (a.ups != 0 && a.ups != 1) || tile < 0 || tile > 2 || (a.splitk > 1 && !a.ws) || a.splitk > a.Kp / 64 ||
         variant < 0 || variant > 10 || a.splitk > 64 || (a.CinP % 128 != 0 && (variant == 6 || variant == 7))) {
         l2d_set_error("igemm(tag %d): invalid arguments (taps=%d C1=%d C2=%d CinP=%d M=%d Nout=%d ldo=%d splitk=%d tile=%d zero=%p)",
