@@ -489,11 +489,15 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
         float *slab = a.ws + ((z * nwg + wgid) * S) * (long long)(TN * TM);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, S * TN * TM * 4, 0x00020000);
         const int mine = ((int)blockIdx.y * (TN * TM) + tid * 4) * 4;          // byte offsets inside the tile's slab
+        // (fragments whose 16 token rows all lie beyond M -- most of a tile at the 8x8 level -- are neither parked nor summed:
+        // wave-uniform test, the same on both sides)
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int j = 0; j < MI; ++j) {
+            if (m0 + wm * (TM / 2) + j * 16 >= a.M) continue;
 #pragma unroll
-            for (int j = 0; j < MI; ++j)
+            for (int i = 0; i < NI; ++i)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, mine + (i * MI + j) * 4096, 0, AUX_SC1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's partials have been written through ...
         __syncthreads();                                    // ... every thread's have
         unsigned int *flag = reinterpret_cast<unsigned int *>(smem);
@@ -507,13 +511,16 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int y = 0; y < S; ++y) {
-            const int src = (y * (TN * TM) + tid * 4) * 4;
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+        for (int j = 0; j < MI; ++j) {
+            if (m0 + wm * (TM / 2) + j * 16 >= a.M) continue;
+#pragma unroll 4
+            for (int y = 0; y < S; ++y) {                   // (unrolled: four slabs of loads in flight; the sum keeps its order)
+                const int src = (y * (TN * TM) + tid * 4) * 4;
 #pragma unroll
-                for (int j = 0; j < MI; ++j)
+                for (int i = 0; i < NI; ++i)
                     acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, src + (i * MI + j) * 4096, 0, AUX_SC1));
+            }
         }
         if (vec && RES_EARLY) load_early();
     } else if (split) {

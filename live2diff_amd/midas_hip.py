@@ -219,11 +219,13 @@ class HipMidas:
             if tile == 1 and variant in (7, 8, 9):
                 variant = 5
             ws, cnt_kw = None, {}
-            if S > 1:
+            if ops.splitk_fused(S):
                 n_ws, n_cnt = ops.splitk_sizes(kw["M"], kw["Nout"], S, kw.get("batch", 1), tile)
                 ws = ar.alloc(n_ws, torch.float32)
                 cnt_kw = dict(cnt=st.sk_cnt, cnt_off=st.sk_used)
                 st.sk_used += n_cnt
+            elif S > 1:
+                ws = ar.alloc(kw.get("batch", 1) * S * kw["M"] * round_up(kw["Nout"], 4), torch.float32)
             op = add(ops.igemm(x, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, **cnt_kw, **kw))
             ar.release(ws)
             return op

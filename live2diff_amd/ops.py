@@ -205,6 +205,12 @@ def splitk_sizes(M: int, Nout: int, splitk: int, batch: int, tile: int):
 
 
 SPLITK_FUSED = os.environ.get("L2D_IGEMM_SPLITK_FUSED", "1") != "0"     # A/B knob: 0 = separate reduction launch (round 1)
+SPLITK_FUSED_MAX = int(os.environ.get("L2D_IGEMM_SPLITK_FUSED_MAX", "16"))     # deeper splits keep the reduction launch: ONE block
+# per tile sums all S slabs in the fused form, which serialises when a launch has few tiles and many splits (8x8 levels)
+
+
+def splitk_fused(splitk: int) -> bool:
+    return SPLITK_FUSED and 1 < splitk <= SPLITK_FUSED_MAX
 
 
 def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):

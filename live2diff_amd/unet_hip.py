@@ -339,7 +339,7 @@ class HipStreamingUNet:
             if epi == 1:
                 S = 1                  # GEGLU pairs value and gate in one block's registers: no split-K
             ws, cnt_kw = None, {}
-            if S > 1 and ops.SPLITK_FUSED:
+            if ops.splitk_fused(S):
                 n_ws, n_cnt = ops.splitk_sizes(kw["M"], kw["Nout"], S, batch, tile)
                 ws = ar.alloc(n_ws, torch.float32)
                 cnt_kw = dict(cnt=st.sk_cnt, cnt_off=st.sk_used)

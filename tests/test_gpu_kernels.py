@@ -107,7 +107,8 @@ def test_igemm_swapped_batched(L):
 
 
 @pytest.mark.parametrize("M,K,N,S,tile", [(128, 2560, 1280, 8, 1), (512, 1280, 320, 4, 2), (2048, 640, 640, 2, 1),
-                                          (300, 1024, 70, 5, 2), (128, 11520, 256, 24, 1)])
+                                          (300, 1024, 70, 5, 2), (128, 11520, 256, 24, 1), (16, 2560, 1280, 8, 1),
+                                          (16, 5120, 640, 32, 2), (80, 2560, 320, 7, 1)])
 @pytest.mark.parametrize("fused", [False, True])
 def test_igemm_splitk(L, M, K, N, S, tile, fused):
     """fused: the last-arriving block of a tile reduces the S partial tiles (fixed order) and runs the epilogue -- one launch;

@@ -12,3 +12,4 @@ for cfgs in "256 256 1 12" "512 768 2 24" "512 512 4 16" "576 1024 2 40"; do set
 import json
 d=json.loads(open('gpurun_out/$TAG/bench_$1x$2_n$3_L$4.json').read().strip().splitlines()[-1]); print(d['config']['workload'][:60], d['value'], d['ms_per_step'], d['config']['kv_cache_GB_per_stream'], (d.get('whole_frame') or {}).get('frames_per_s'))"
 done
+timeout 200 python tools/midas_time.py 1 > gpurun_out/$TAG/${TAG}_midas_time.json 2>> gpurun_out/$TAG/bench_other.err; cat gpurun_out/$TAG/${TAG}_midas_time.json
