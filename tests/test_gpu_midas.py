@@ -244,3 +244,46 @@ def test_pipeline_encode_depth_with_hip_detector():
         floor = rel(glue_ref(M.midas_forward(x384.float().cpu(), sd32)), ref)
     torch.cuda.synchronize()
     assert out.shape == (1, 3, 512, 512) and rel(out, ref) <= max(1e-2, 2 * floor), (rel(out, ref), floor)
+
+
+def test_whole_pipeline_on_hip_backends():
+    """Every per-frame model slot of StreamAnimateDiffusionDepth filled by this repo (`stream.unet` HipStreamingUNet,
+    `stream.vae` HipTinyVAE, `stream.depth_detector` HipMidas, HIP depth glue), host-driven frame step and device step:
+    `prepare` over the warm-up window + frames run, stay finite, and the two stepping modes agree bit for bit (no re-noising,
+    so neither path draws random numbers after `prepare`)."""
+    from types import SimpleNamespace
+
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.midas_hip import HipMidas, random_midas_state_dict
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.vae_hip import HipTinyVAE, random_taesd_state_dict
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    H = W = 128
+    sd = {k: v.to(DEV) for k, v in random_state_dict(cfg, dtype=torch.float16).items()}
+    vae = HipTinyVAE(random_taesd_state_dict(), device=DEV)
+    det = HipMidas(random_midas_state_dict(), device=DEV)
+    g = torch.Generator().manual_seed(8)
+    warm = [torch.rand(3, H, W, generator=g) for _ in range(cfg.sink_size)]
+    frames = [torch.rand(1, 3, H, W, generator=g) for _ in range(5)]
+    emb = torch.randn(1, 77, 64, generator=g)
+    outs = []
+    for device_step in (False, True):
+        torch.manual_seed(0)
+        pipe = SimpleNamespace(device=torch.device(DEV), vae_scale_factor=8, unet=HipStreamingUNet(sd, cfg, H // 8, W // 8, 2), vae=vae,
+                               depth_model=det, scheduler=None)
+        s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=[30, 40], width=W, height=H, do_add_noise=False,
+                                        warmup_frames=cfg.sink_size, window_size=cfg.window_size)
+        s.prepare_cache(H, W, 2)
+        first = s.prepare(warm, prompt_embeds=emb, seed=3)
+        if device_step:
+            s.enable_device_step()
+        res = [s(f.to(DEV)).clone() for f in frames]
+        assert first.shape == (cfg.sink_size, 3, H, W) and torch.isfinite(first).all()
+        assert all(r.shape == (1, 3, H, W) and torch.isfinite(r).all() for r in res)
+        assert float(torch.stack(res).std()) > 1e-3                           # the frames are not a constant image
+        outs.append([first] + res)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), f"frame {i}: host-driven step and device step differ"
+    assert det.plan_summary().keys() >= {(1, 384, 384), (cfg.sink_size, 384, 384)}      # per-frame call and the warm-up batch

@@ -17,6 +17,8 @@ from live2diff_amd import _lib, ops                                             
 DEV = "cuda"
 SHAPES = [  # (name, taps, M, N, K(Cin), tile, S, variant, epi, res)
     ("CxC level0", 1, 8192, 320, 320, 2, 1, 1, 0, True),
+    ("CxC level0 v8 (1 block/CU)", 1, 8192, 320, 320, 2, 1, 8, 0, True),
+    ("CxC level0 256 rows only", 1, 4096, 320, 320, 2, 1, 1, 0, True),
     ("CxC level1", 1, 2048, 640, 640, 2, 1, 1, 0, True),
     ("CxC level2", 1, 512, 1280, 1280, 2, 1, 7, 0, True),
     ("CxC level3", 1, 128, 1280, 1280, 2, 3, 1, 0, True),
@@ -63,7 +65,12 @@ def main():
         torch.cuda.synchronize()
         _lib.lib.l2d_igemm_set_probe(None)
         p = probe.view(nblk, 8).cpu()
-        p = p[(p > 0).all(1)]                                  # (split-K: only the reducing block of a tile reaches stamps 5-7)
+        for c in range(1, 8):                                   # a stamp that was not reached (e.g. "first stage landed" when the
+            p[:, c] = torch.where(p[:, c] > 0, p[:, c], p[:, c - 1])   # whole K range fits the prologue) counts as zero time
+        p = p[p[:, 0] > 0]
+        if p.shape[0] == 0:
+            print(name, "no stamps recorded")
+            continue
         names = ["w_issue", "desc+prologue", "first_stage_wait", "k_loop", "to_lds", "stores", "gn+end"]
         # the counter is per XCD (not synchronised across XCDs): order blocks by entry time within their own clock domain
         # (domains show up as clusters > 1e9 apart) and report early / late blocks of the largest cluster separately
