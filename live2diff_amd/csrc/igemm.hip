@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
 
     // Touch every 64-byte line of the argument block NOW (four throw-away scalar loads, all in flight together): the
     // compiler fetches arguments where they are first used, which made the path to the first DMA a chain of 4-5 dependent
-    // scalar-cache misses.  The destination registers stay reserved until the `asm("")` below the first DMA issue; the
+    // scalar-cache misses.  The destination registers stay reserved until the asm statement below the first DMA issue; the
     // compiler's own lgkmcnt(0) waits in between cover these loads too (the counter is per wave, not per instruction).
     unsigned ka0, ka1, ka2, ka3;
     {
@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
     // (cold: the previous kernel's end flushed the L2s) memory round trip instead of in front of it.
     if (kb < ke) issue_w();
     L2D_STAMP(1);                                       // first weight stage issued
-    asm volatile("" ::"s"(ka0), "s"(ka1), "s"(ka2), "s"(ka3));      // (end of the warm-up registers' reservation)
+    // end of the warm-up registers' reservation.  The explicit wait is free here (the first DMA needed the arguments, so the
+    // compiler has already waited for every scalar load) and makes the "loads have landed before the registers are reused"
+    // guarantee independent of the compiler's scheduling.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(ka0), "s"(ka1), "s"(ka2), "s"(ka3));
     const h16 *x1 = a.x1 + z * a.sx1;
     h16 *outp = a.out + z * a.so;
     const h16 *resp = a.res ? a.res + z * a.sres : nullptr;
