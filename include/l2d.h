@@ -85,7 +85,8 @@ enum {
  *   i0 B i1 H i2 d i3 Tq i4 Tk i5 ldq i6 ldk i7 ldvt i8 ldo ; l0 q batch stride l1 k l2 vt l3 out
  *   p4 16-byte zero page (DMA source of keys beyond Tk; 0 selects the register-staged kernel)
  *   i9 variant: 0 auto (LDS-DMA ring kernel, flash_attn_ring.hip), 1 register-staged kernel, 2 / 3 ring kernel with
- *   32 / 16 query rows per wave.  V^T columns in [Tk, ldvt) may hold anything.
+ *   32 / 16 query rows per wave, 4 / 5 further geometries (8 waves; 2-deep ring), 6 software-pipelined across key tiles
+ *   (d <= 40; measured slower than 2, kept selectable for A/B).  V^T columns in [Tk, ldvt) may hold anything.
  *
  * L2D_OP_TATTN_STREAM  fused streaming temporal attention with multi-timestep KV-cache
  *                (reference stream_motion_module.py:99-213)
