@@ -44,7 +44,23 @@ struct FARArgs {
     h16 *out;
     int B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, xcd;
     long long sq, sk, svt, so;
+#ifdef L2D_PROBES
+    unsigned long long *probe;   // analysis builds: s_memtime stamps of key tiles 8 and 9, every wave (tools/flash_probe.py)
+#endif
 };
+
+#ifdef L2D_PROBES
+static unsigned long long *g_flash_probe = nullptr;
+extern "C" void l2d_flash_set_probe(void *p) { g_flash_probe = (unsigned long long *)p; }
+// stamp i (0..7) of this wave: [block][wave][8]
+#define FAR_STAMP(kt, i)                                                                                         \
+    do {                                                                                                         \
+        if (a.probe && (kt) == 8 && (threadIdx.x & 63) == 0)                                                      \
+            a.probe[((unsigned long long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define FAR_STAMP(kt, i) do { } while (0)
+#endif
 
 // max over the 4 lanes {li, li+16, li+32, li+48} that share a query row, without the LDS round trips of ds_bpermute:
 // v_permlane16_swap / v_permlane32_swap exchange half-rows / half-waves between two registers
@@ -251,6 +267,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                         sacc[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qs][kk], kk == 0 ? cinit[qs] : sacc[ks][qs], 0, 0, 0);
                 }
         }
+        FAR_STAMP(kt, 1);                                                 // QK^T issued
         if (LAST && (kt + 1) * 64 > a.Tk) {                               // keys beyond Tk exist in the last tile only
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -268,6 +285,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 m = fmaxf(fmaxf(m, fmaxf(sacc[ks][qs][0], sacc[ks][qs][1])), fmaxf(sacc[ks][qs][2], sacc[ks][qs][3]));
             mx[qs] = far_row_max(m);
         }
+        FAR_STAMP(kt, 2);                                                 // row maxima known
         // sacc already is  s*c - mref.  Raise the reference (rarely after the first tile): everything still at the old
         // reference -- O, l and THIS tile's not yet exponentiated scores -- is moved to the new one exactly once.  A subtile
         // whose maximum did not grow gets delta = 0, alpha = 1: the same code path, exact.
@@ -326,6 +344,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                         oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf[c2][qs], oacc[ds][qs], 0, 0, 0);
                 }
         }
+        FAR_STAMP(kt, 3);                                                 // exp + PV issued
         cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
     };
 
@@ -362,9 +381,14 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         kt = 1;
     }
     for (; kt + NS < nt; ++kt) {           // refills of tiles < nt - 1: no bounds test anywhere in this loop
+        FAR_STAMP(kt, 4);                  // (loop top of tile 8; the same stamp taken for tile 9 closes the period)
+        FAR_STAMP(kt - 1, 7);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        FAR_STAMP(kt, 5);                  // own DMA share landed
         __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; everyone finished tile kt-1
+        FAR_STAMP(kt, 6);                  // barrier passed
         issue(F_{});                       // refill the ring slot tile kt-1 occupied
+        FAR_STAMP(kt, 0);                  // DMA issued
         compute(kt, F_{}, F_{});
     }
     for (; kt + (NS - 1) < nt; ++kt) {     // the one refill that fetches the last tile
@@ -824,6 +848,9 @@ int l2d_launch_flash_ring(const l2d_op *op, int geo, hipStream_t s) {
     FARArgs a;
     a.q = (const h16 *)op->p[0]; a.k = (const h16 *)op->p[1]; a.vt = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
     a.zero = (const h16 *)op->p[4];
+#ifdef L2D_PROBES
+    a.probe = g_flash_probe;
+#endif
     static int xcd_order = -1;          // A/B knob: L2D_FLASH_XCD=0 keeps the plain (q-block fastest) block order
     if (xcd_order < 0) {
         const char *e = getenv("L2D_FLASH_XCD");
