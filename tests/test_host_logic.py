@@ -355,3 +355,29 @@ def test_prepare_and_call_chain_match_reference_capture(golden, monkeypatch, n, 
     assert torch.equal(s.update_idx, T("update_idx"))
     assert torch.equal(torch.stack([c["t"] for c in pipe.unet.log]), T("unet_t"))
     assert torch.equal(torch.stack([c["update_idx"] for c in pipe.unet.log]), T("unet_update_idx"))
+
+
+def test_float_assisted_division_is_exact():
+    """igemm.hip `l2d_divf`: q = int(float(n) * (1.0f / d)), one correction step either way -- the kernels' tile / pixel index
+    arithmetic relies on it being EXACT for 0 <= n < 2^24 (validated range).  Emulated here in IEEE fp32 (numpy), on the values the
+    plans use (token counts, tile counts, image widths, split counts) and on random / adversarial operands."""
+    rng = np.random.default_rng(0)
+
+    def divf(n, d):
+        inv = (np.float32(1.0) / d.astype(np.float32)).astype(np.float32)
+        q = (n.astype(np.float32) * inv).astype(np.int64)                 # (int) truncation of a non-negative float
+        r = n - q * d
+        return q + (r >= d).astype(np.int64) - (r < 0).astype(np.int64)
+
+    n = rng.integers(0, 1 << 24, size=2_000_000, dtype=np.int64)
+    d = rng.integers(1, 1 << 20, size=n.size, dtype=np.int64)
+    assert np.array_equal(divf(n, d), n // d)
+    # adversarial: n = k*d - 1, k*d, k*d + 1 around every multiple, small and large divisors, and the largest numerators
+    for dd in (1, 2, 3, 5, 7, 9, 10, 12, 24, 63, 64, 65, 96, 127, 128, 320, 576, 577, 1024, 4095, 4096, 4097, 9216, 65535, 65537, 1 << 20):
+        k = np.arange(0, min((1 << 24) // dd, 200_000) + 1, dtype=np.int64)
+        for off in (-1, 0, 1):
+            nn = k * dd + off
+            nn = nn[(nn >= 0) & (nn < (1 << 24))]
+            assert np.array_equal(divf(nn, np.full_like(nn, dd)), nn // dd), dd
+        top = np.arange((1 << 24) - 100_000, 1 << 24, dtype=np.int64)
+        assert np.array_equal(divf(top, np.full_like(top, dd)), top // dd), dd
