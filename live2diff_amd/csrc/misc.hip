@@ -269,3 +269,77 @@ extern "C" int l2d_read_bench(const void *src, void *sink, int64_t bytes, int un
     *gbps_out = (float)((double)n16 * 16.0 * reps / (ms * 1e-3) / 1e9);
     return l2d_check_launch("read_bench", 0);
 }
+
+#ifdef L2D_PROBES
+// Access-pattern probe for the KV-cache stream (analysis builds only, tools/kv_pattern_probe.py).  One 320-thread block per CU
+// streams its private slice of `src` HBM -> LDS with the ring discipline of tattn_ring.hip (NS stages of R DMA wave-instructions,
+// counted vmcnt waits, one barrier per stage) and NO arithmetic.  `pattern` picks what a stage fetches from a group of 8 pixels
+// x 16 rows x 640 B (= 80 KB contiguous, the [pixel][slot][channel] slab of the reference layout at C = 320):
+//   0  rows 4s .. 4s+3 of all 8 pixels: 8 pieces of 2.5 KB at 10 KB stride (what tattn_ring.hip does)
+//   1  all 16 rows of pixels 2s, 2s+1: one contiguous 20 KB run
+//   2  the group read front to back, 20 KB per stage (the same bytes as 1; source order = LDS order)
+// K and V slabs are `slab` bytes apart, visited K (4 stages) then V (4 stages) per group, like the real kernel.
+template <int NS>
+__global__ __launch_bounds__(320) void kv_pattern_kernel(const char *src, unsigned *sink, long long slab, int groups_per_block, int pattern) {
+    constexpr int R = 4, STAGE = R * 320 * 16;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = tid / 40, cc = tid - p * 40;
+    const char *base = src + (long long)blockIdx.x * groups_per_block * 81920;
+    const int total = groups_per_block * 8;
+    int it_issue = 0, slot = 0;
+    auto issue = [&]() {
+        const int g = it_issue >> 3, s = it_issue & 7, sk = s & 3;
+        const char *gb = base + (long long)g * 81920 + (s >= 4 ? slab : 0);
+        char *dst = ring + slot * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            long long off;
+            if (pattern == 0) off = (long long)p * 10240 + (sk * 4 + j) * 640 + cc * 16;
+            else off = (long long)sk * 20480 + (j * 320 + tid) * 16;
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(gb + off),
+                                             (__attribute__((address_space(3))) void *)(dst + j * 320 * 16), 16, 0, 0);
+        }
+        ++it_issue;
+        slot = (slot + 1 == NS) ? 0 : slot + 1;
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (it_issue < total) issue();
+    unsigned acc = 0;
+    int cs = 0;
+    for (int it = 0; it < total; ++it) {
+        if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * R) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it_issue < total) issue();
+        acc ^= *reinterpret_cast<const unsigned *>(ring + cs * STAGE + tid * 16);      // one LDS read per stage keeps the data "used"
+        cs = (cs + 1 == NS) ? 0 : cs + 1;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+extern "C" int l2d_kv_pattern_bench(const void *src, void *sink, int64_t slab, int groups_per_block, int pattern, int blocks, int reps,
+                                    void *stream, float *gbps_out) {
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int NS = 5;
+    const int lds = NS * 4 * 320 * 16;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void *)kv_pattern_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto launch = [&]() { hipLaunchKernelGGL((kv_pattern_kernel<NS>), dim3(blocks), dim3(320), lds, s, (const char *)src, (unsigned *)sink, (long long)slab, groups_per_block, pattern); };
+    launch();
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbps_out = (float)((double)blocks * groups_per_block * 2.0 * 81920.0 * reps / (ms * 1e-3) / 1e9);
+    return l2d_check_launch("kv_pattern_bench", 0);
+}
+#endif
