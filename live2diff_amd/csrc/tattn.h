@@ -10,6 +10,9 @@ struct TAttnArgs {
     const h16 *bias;
     h16 *out;
     int N, T, C, L, H, variant;
+#ifdef L2D_PROBES
+    unsigned long long *probe;   // analysis builds: s_memtime stamps of two stages per block (tools/tattn_probe.py)
+#endif
 };
 
 // true when the ring kernel covers the shape: C in {320, 640, 1280}, L in {12, 16}, T % 8 == 0, and the caller gave

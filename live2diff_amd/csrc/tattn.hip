@@ -461,6 +461,12 @@ static int tattn_common(const l2d_op *op, TAttnArgs &a, const char *what) {
     a.pe_idx = (const long long *)op->p[5]; a.update_idx = (const long long *)op->p[6];
     a.bias = (const h16 *)op->p[7]; a.out = (h16 *)op->p[8];
     a.N = op->i[0]; a.T = op->i[1]; a.C = op->i[2]; a.L = op->i[3]; a.H = op->i[4]; a.variant = op->i[5];
+#ifdef L2D_PROBES
+    {
+        extern unsigned long long *l2d_tattn_probe_ptr();
+        a.probe = l2d_tattn_probe_ptr();
+    }
+#endif
     if (!a.qkv || !a.cache || !a.q_pe || !a.k_pe || !a.v_pe || !a.out || a.N <= 0 || a.T <= 0 || a.H != 8 ||
         (a.C % 64) || a.L <= 0) {
         l2d_set_error("%s(tag %d): invalid arguments (N=%d T=%d C=%d L=%d H=%d; need H=8, C%%64==0)", what, op->tag, a.N,

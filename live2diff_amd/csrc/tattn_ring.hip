@@ -36,6 +36,21 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef L2D_PROBES
+static unsigned long long *g_tattn_probe = nullptr;
+extern "C" void l2d_tattn_set_probe(void *p) { g_tattn_probe = (unsigned long long *)p; }
+unsigned long long *l2d_tattn_probe_ptr() { return g_tattn_probe; }
+// stamps of the second pixel group's stage 1 (a K stage) and stage NSTG/2 + 1 (a V stage): [block][wave][2][8]
+#define TR_STAMP(gi, s, i)                                                                                          \
+    do {                                                                                                            \
+        if (a.probe && (gi) == 1 && ((s) == 1 || (s) == NSTG / 2 + 1) && (threadIdx.x & 63) == 0)                    \
+            a.probe[(((unsigned long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + ((s) == 1 ? 0 : 1)) * 8 + (i)] = \
+                __builtin_readcyclecounter();                                                                       \
+    } while (0)
+#else
+#define TR_STAMP(gi, s, i) do { } while (0)
+#endif
+
 // dot product on v_dot2_f32_f16: two exact fp16 products + fp32 accumulate per instruction
 __device__ __forceinline__ float ring_dot8(h16x8 a, h16x8 b) {
     float s = 0.f;
@@ -57,16 +72,20 @@ __device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
 // HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) = 100 KB of ring, one block per CU;
 // (2, 3) = 30 KB, TWO blocks per CU (76 KB each): ten waves instead of five on the CU's four SIMDs (the loop is issue bound on
 // the SIMD that hosts two of a block's five waves) and one block's DMA under the other's arithmetic.
-template <int HG, int L, int R, int NS>
-__global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
-    constexpr int TP = 40, PB = 8, NSTG = 2 * L / R, LPS = R;
-    constexpr int STAGE_H = R * PB * TP * 8;       // halfs per stage (20 KB)
+// PB = pixels per group = 8 (320 threads, 5 waves) or 16 (640 threads, 10 waves: 3/3/2/2 over the four SIMDs instead of
+// 2/1/1/1 -- the loop is instruction-issue bound on the fullest SIMD, tools/kv_pattern_probe.py shows the DMA side alone at
+// 6.2 TB/s).  Everything per pixel is unchanged; the stage (R rows x PB pixels), the score rows and the DMA images scale with
+// the block size NT = 40 PB, the PE rows and the per-row constants are shared.
+template <int HG, int L, int R, int NS, int PB>
+__global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
+    constexpr int TP = 40, NT = TP * PB, NSTG = 2 * L / R, LPS = R;
+    constexpr int STAGE_H = R * PB * TP * 8;       // halfs per stage (20 KB at R = 4, PB = 8)
     constexpr int LP = L + 4;
-    // LDS: ring [NS][20 KB] | score rows [320][LP] f32 | bias of row n [L] f32 | k_pe rows [L][40][8] | v_pe rows
+    // LDS: ring [NS][stage] | score rows [NT][LP] f32 | bias of row n [L] f32 | k_pe rows [L][40][8] | v_pe rows
     extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
     h16 *ring = reinterpret_cast<h16 *>(ring_raw);
     float *sp = reinterpret_cast<float *>(ring_raw + (size_t)NS * STAGE_H * sizeof(h16));
-    float *blds = sp + 320 * LP;
+    float *blds = sp + NT * LP;
     h16 *kpl = reinterpret_cast<h16 *>(blds + L);
     h16 *vpl = kpl + L * 320;
 
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
     // gathered PE rows of this chunk -> LDS by DMA (older than every ring load: landed before the first stage is
     // consumed, visible to the block after that stage's barrier).  L * 40 items of 16 B per table.
 #pragma unroll
-    for (int f0 = 0; f0 < L * TP; f0 += 320) {
+    for (int f0 = 0; f0 < L * TP; f0 += NT) {
         const int f = f0 + tid;
         if (f < L * TP) {
             const int l = f / TP, c = f - l * TP;
@@ -124,13 +143,21 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
         const h16 *cb = (isv ? vbase : kbase) + (long long)is_g * (PB * L * C);
         const h16 *qb = qkv_b + (long long)is_g * (PB * 3 * C) + (isv ? 2 * C : C);
         h16 *dst = ring + is_slot * STAGE_H + wave * 512;
+        // Source of row l: the cache (live slot), the new projection row (slot u) or the zero page (masked slot).  All three
+        // conditions are wave-uniform, but written as if / else the compiler emits three taken-or-not branches and re-materialised
+        // 64-bit pointers per row (~28 instructions between two DMAs: the stage probe showed 800-1000 cycles for these four
+        // loads, as much as the stage's arithmetic).  Branch-free instead: masks on the scalar unit select the 64-bit base, two
+        // VALU ANDs select the per-thread offset.
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
             const int l = l0 + j;                                // uniform
-            const h16 *src = zero;
-            if ((live >> l) & 1) src = cb + l * C + coff;
-            else if (l == u) src = qb + qoff;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst + j * 320 * 8), 16, 0, 0);
+            const unsigned long long lv = 0ull - (unsigned long long)((live >> l) & 1u);        // all ones: live slot
+            const unsigned long long nw = (0ull - (unsigned long long)(l == u ? 1u : 0u)) & ~lv; // all ones: the new row
+            const unsigned long long sb = ((unsigned long long)(cb + l * C) & lv) | ((unsigned long long)qb & nw) |
+                                          ((unsigned long long)zero & ~(lv | nw));
+            const unsigned vo = (coff & (unsigned)lv) | (qoff & (unsigned)nw);
+            const h16 *src = reinterpret_cast<const h16 *>(sb) + vo;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst + j * NT * 8), 16, 0, 0);
         }
         ++it_issue;
         if (++is_s == NSTG) { is_s = 0; ++is_g; }
@@ -159,16 +186,20 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
         for (int s = 0; s < NSTG; ++s) {
             // stage `it` has landed when at most NS-2 younger stages are outstanding (in-order return; other VMEM ops
             // in flight only make this wait longer, never shorter)
+            TR_STAMP(gi, s, 0);                                  // stage top
             if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            TR_STAMP(gi, s, 1);                                  // own DMA share of this stage landed
             __builtin_amdgcn_s_barrier();
+            TR_STAMP(gi, s, 2);                                  // barrier passed
             if (it_issue < total) issue();                       // refills the slot every wave finished one stage ago
+            TR_STAMP(gi, s, 3);                                  // refill issued
             const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
             if (s < NSTG / 2) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int l = s * R + r;
-                    h16x8 kk = l2d_ld8(st + r * 320 * 8);        // masked slots hold zeros
+                    h16x8 kk = l2d_ld8(st + r * NT * 8);         // masked slots hold zeros
                     if (l == u) l2d_st8(ku + coff, kk);          // cache keeps the pre-PE projections (:117-119)
                     kk = kk + l2d_ld8(kpt + l * 320);            // fp16 rounding of K+pe as in the reference (:140)
                     sc[l] = ring_dot8(q8, kk);
@@ -210,12 +241,13 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int l = (s - NSTG / 2) * R + r;
-                    h16x8 vv = l2d_ld8(st + r * 320 * 8);
+                    h16x8 vv = l2d_ld8(st + r * NT * 8);
                     if (l == u) l2d_st8(ku + slab + coff, vv);
                     vv = vv + l2d_ld8(vpt + l * 320);            // (:141)
                     ring_axpy8(o, sc[l], vv);
                 }
             }
+            TR_STAMP(gi, s, 4);                                  // stage arithmetic issued
             ++it;
             cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
         }
@@ -226,34 +258,44 @@ __global__ __launch_bounds__(320) void tattn_stream_ring_kernel(TAttnArgs a, con
     }
 }
 
-template <int L, int HG, int R, int NS>
+template <int L, int HG, int R, int NS, int PB>
 static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
-    constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(320 * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
+    constexpr int NT = 40 * PB;
+    constexpr size_t LDS = (size_t)NS * R * PB * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
+    static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
     static bool attr_done = false;
     if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel (not inside a stream capture: the
         // plan's first run is always direct; on failure the flag stays clear and the launch below reports the error)
-        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
     }
     const int CH = a.C / 320;
-    const int groups_per_unit = a.T / 8;
+    const int groups_per_unit = a.T / PB;
     const int total = a.N * CH * groups_per_unit;
     const int gpb = (total + slots - 1) / slots;   // LDS-filling blocks, persistent over gpb pixel groups
     const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(320), LDS, s, a, zero, gpb, groups_per_unit);
+    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS, PB>), dim3(a.N * CH * bpu), dim3(NT), LDS, s, a, zero, gpb, groups_per_unit);
 }
 
 template <int L, int HG>
 static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
-    static int geo = -1;                 // tuning knob L2D_TATTN_RING: 0 = (4 rows, 5 stages, 1 block / CU), 1 = (2, 3, 2 blocks / CU)
-    if (geo < 0) {
+    // tuning knob L2D_TATTN_RING: -1 auto; 0 = 8 pixels, (4 rows, 5 stages), 1 block / CU; 1 = 8 pixels, (2, 3), 2 blocks / CU;
+    // 2 = 16 pixels (10 waves), (2 rows, 4 stages), 1 block / CU
+    static int geo = -2;
+    if (geo == -2) {
         const char *e = getenv("L2D_TATTN_RING");
-        geo = e ? atoi(e) : 0;
+        geo = e ? atoi(e) : -1;
     }
-    if (geo == 1) launch_ring_g<L, HG, 2, 3>(a, zero, 2 * cus, s);
-    else launch_ring_g<L, HG, 4, 5>(a, zero, cus, s);
+    int g = geo;
+    const long long groups16 = (long long)a.N * (a.C / 320) * (a.T / 16);
+    if (g == -1) g = 0;
+    (void)groups16;
+    if (g == 2 && a.T % 16 != 0) g = 0;
+    if (g == 1) launch_ring_g<L, HG, 2, 3, 8>(a, zero, 2 * cus, s);
+    else if (g == 2) launch_ring_g<L, HG, 2, 4, 16>(a, zero, cus, s);
+    else launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s);
 }
 
 bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
