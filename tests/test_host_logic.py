@@ -167,6 +167,32 @@ def test_plan_validates_sd15_shapes(dry_run):
     assert abs(unet.weight_bytes() / 1e9 - 2.6) < 0.2
 
 
+@pytest.mark.parametrize("name,h,w,N,L,S", [("cfg-1", 32, 32, 1, 12, 4), ("cfg-3", 64, 96, 2, 24, 8), ("cfg-4", 64, 64, 4, 16, 8),
+                                             ("cfg-5", 72, 128, 2, 40, 8)])
+def test_plan_validates_other_baseline_configs(dry_run, name, h, w, N, L, S):
+    """The other BASELINE.json configurations at SD-1.5 widths: stream and warm-up plans build from the heuristic schedule
+    (their shapes are not in the cfg-2 table: deep split-K at the 4x4 / 8x8 levels, long windows on the chunked temporal kernel,
+    ragged token counts) and every op passes the C library's validation; split launches beyond 16 splits keep the separate
+    reduction launch (igemm.hip: one block per tile would serialise the fused form)."""
+    from live2diff_amd import _lib, ops
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import unet_param_spec
+    cfg = sd15_config(window_size=L, sink_size=S)
+    sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    unet = HipStreamingUNet(sd, cfg, h, w, N, device="cpu")
+    del sd
+    kv = unet.prepare_cache(N)
+    for mode in ("stream", "warmup"):
+        st = unet._plan(mode, kv)
+        st.pl.run(stream=0)
+        st.cond_pl.run(stream=0)
+        splits = [(op.i[21], bool(op.p[11])) for op in st.pl._ops if op.kind == _lib.OP_IGEMM and op.i[21] > 1]
+        assert all(fused == (S_ <= ops.SPLITK_FUSED_MAX) for S_, fused in splits), (name, mode, splits)
+        assert st.sk_used <= st.sk_cnt.numel()
+    assert unet.plan_summary("stream")["gn_fused"] >= 40        # (levels whose tokens per sample are no multiple of the tile keep the statistics kernel)
+
+
 def test_device_step_plan_validates_without_gpu(dry_run):
     """HipStreamStep (UNet plan + randn + stream_shift + ring_update as one op list) built on CPU
     tensors; every op passes the C library's validation, and malformed glue ops are refused."""
