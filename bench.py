@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+MFMA_KERNELS = ("igemm_kernel", "rowgemm_kernel", "flash_attn_kernel")   # kernel families priced against the MFMA roofline
 
 
 # (height, width, denoise steps, window L) of the BASELINE.json configurations the GPU leg can run
@@ -279,7 +280,11 @@ def main():
     from live2diff_amd.weights import device_random_state_dict, random_state_dict, unet_param_spec
 
     rank, world, local = parallel.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks. Launch with `python -m "
+              f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`, or run `python "
+              f"bench.py --gpus {args.gpus}` from a bare shell (it launches the ranks itself).", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     sink = args.sink or (4 if args.window == 12 else 8)
@@ -438,6 +443,18 @@ def main():
                    "timed_region": ("pipeline step on the device: UNet + LCM step + shift + noise + ring buffer (row F3)"
                                     if args.device_step else "UNet boundary call (+ host ring buffer and its upload)")},
     }
+    my_frac = float("nan")
+    if args.breakdown and rank != 0 and world > 1:
+        # every rank replays its own kernel families: the N > 1 line carries each GPU's roofline fraction
+        try:
+            rows = per_kernel_breakdown(unet)
+            name, r = max(rows.items(), key=lambda kv_: kv_[1]["ms"])
+            if r["flops"] > 0 and name in MFMA_KERNELS:
+                my_frac = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS
+            else:
+                my_frac = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        except Exception:  # noqa: BLE001
+            pass
     if rank == 0 and args.breakdown:
         rows = per_kernel_breakdown(unet)
         tot = sum(r["ms"] for r in rows.values())
@@ -458,14 +475,17 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = (json.load(open(tpath)).get(name) or {}).get("hbm_bytes_per_launch")
-        if name in ("igemm_kernel", "flash_attn_kernel"):
+        tsrc = ("static: profiles/traffic.json = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
+                "not collected inside this run") if traffic is not None else None
+        if name in MFMA_KERNELS:
             ach = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12
             result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc}
         else:
             ach = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9
             result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic}
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc}
+        my_frac = result["roofline"]["frac"]
         # the HBM-bound streaming KV-cache kernel is the one north_star singles out: always report it too
         t = rows.get("tattn_stream_kernel")
         if t:
@@ -493,6 +513,8 @@ def main():
             del a, b
         except Exception as e:  # noqa: BLE001
             result["hbm_copy_gbps_measured"] = f"error: {e}"
+    if world > 1 and args.breakdown:
+        result["per_rank_roofline_frac"] = [round(v, 4) for v in parallel.gather_floats(my_frac, device=dev)]
     if rank == 0 and args.per_op:
         per_op_table(unet, args.per_op)
     if rank == 0 and args.dump_plan:

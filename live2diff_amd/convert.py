@@ -110,7 +110,7 @@ def merge_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], al
         if "conv_in" in name:
             # the streaming UNet's conv_in may be wider than the LoRA's 4 input channels: only the first 4 are touched (:75-81)
             delta = (u.reshape(u.shape[0], -1) @ d.reshape(d.shape[0], -1)).reshape(w.shape[0], 4, *w.shape[2:])
-            w32 = w.to(torch.float32)
+            w32 = w.to(torch.float32).clone()          # (never the caller's tensor: `.to` is a no-op on fp32 weights)
             w32[:, :4] += alpha * delta
         elif "conv" in name:
             delta = (u.reshape(u.shape[0], -1) @ d.reshape(d.shape[0], -1)).reshape(w.shape)
@@ -125,13 +125,101 @@ def merge_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], al
     return touched
 
 
+def merge_motion_checkpoint(sd: Dict[str, torch.Tensor], ckpt: Dict) -> List[str]:
+    """In place: the `live2diff.ckpt` merge of the reference (animatediff/pipeline/pipeline_animatediff_depth.py:281-290):
+    take `ckpt["state_dict"]` when present, strip `module.` from the keys, drop the `grid` buffers, load the rest over the
+    UNet weights (`load_state_dict(strict=False)` + the reference's `assert len(unexpected) == 0`).  Returns the keys set."""
+    state = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    state = {k.replace("module.", ""): v for k, v in state.items() if "grid" not in k and torch.is_tensor(v)}
+    unexpected = [k for k in state if k not in sd]
+    if unexpected:
+        raise KeyError(f"Find unexpected keys ({len(unexpected)}): {unexpected[:5]}")
+    for k, v in state.items():
+        if tuple(v.shape) != tuple(sd[k].shape):
+            raise ValueError(f"{k}: checkpoint tensor {tuple(v.shape)} != UNet parameter {tuple(sd[k].shape)}")
+        sd[k] = v.to(sd[k].dtype)
+    return list(state)
+
+
+_DOWN_TAGS = (".lora_down.weight", ".lora.down.weight", ".lora_A.weight", "_lora.down.weight")
+_UP_OF = {".lora_down.weight": ".lora_up.weight", ".lora.down.weight": ".lora.up.weight", ".lora_A.weight": ".lora_B.weight",
+          "_lora.down.weight": "_lora.up.weight"}
+
+
+def few_step_lora_pairs(lora_sd: Dict[str, torch.Tensor]):
+    """(state-dict weight key candidate, up, down, alpha or None) for every UNet pair of a few-step (LCM) LoRA file.  The
+    published `latent-consistency/lcm-lora-sdv1-5` file is kohya-keyed (`lora_unet_<flattened module>.lora_down.weight` +
+    `.alpha`); diffusers 0.25.0's loader (the third-party code behind wrapper.py:451-452 -> pipeline/loader.py:12-31,
+    `LoraLoaderMixin.lora_state_dict`) also accepts its own layouts, which are resolved here too:
+    `unet.<module>.lora.down.weight`, `unet.<module>.lora_A.weight` (peft) and the attention-processor form
+    `unet.<block>.attn1.processor.to_q_lora.down.weight`.  The first tuple element is the flattened (underscore) module
+    name for kohya keys and the dotted module path otherwise."""
+    for k, down in lora_sd.items():
+        tag = next((t for t in _DOWN_TAGS if k.endswith(t)), None)
+        if tag is None or "text" in k.split(".")[0]:
+            continue
+        up = lora_sd[k[: -len(tag)] + _UP_OF[tag]]
+        stem = k[: -len(tag)]
+        if stem.startswith("lora_unet_"):
+            yield ("flat", stem[len("lora_unet_"):], up, down, lora_sd.get(stem + ".alpha"))
+            continue
+        if stem.startswith("lora_te"):
+            continue
+        if stem.startswith("unet."):
+            stem = stem[len("unet."):]
+        stem = stem.replace(".processor.", ".")                     # attn1.processor.to_q(_lora) -> attn1.to_q
+        if stem.endswith("to_out"):
+            stem += ".0"                                           # processor form names the Sequential, the weight is its [0]
+        yield ("dotted", stem, up, down, lora_sd.get(k[: -len(tag)] + ".alpha"))
+
+
+def merge_few_step_lora(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, torch.Tensor], lora_scale: float = 1.0,
+                        strict: bool = True) -> List[str]:
+    """In place: `W += lora_scale * (alpha / rank) * up @ down` for every UNet pair -- the arithmetic of diffusers 0.25.0's
+    `fuse_lora` (`LoRACompatibleLinear._fuse_lora` / `LoRACompatibleConv._fuse_lora`: `w + lora_scale * bmm(up, down)` with
+    `network_alpha / rank` folded into `up`), which the reference calls through `stream.load_lora(few_step_lora);
+    stream.fuse_lora()` (wrapper.py:451-452) BEFORE `prepare_cache` projects the positional-encoding tables (:454-459) --
+    so a few-step LoRA that targets motion-module projections must be merged before `HipStreamingUNet` packs the weights,
+    which is exactly where `build_state_dict` puts it.  diffusers is not in /root/reference: **parity unpinned**, checked
+    against the formula (tests/test_convert.py).  Unresolved modules raise with strict=True (default), like the loader."""
+    flat = {_flatten(k[: -len(".weight")]): k for k in sd if k.endswith(".weight")}
+    touched = []
+    for kind, name, up, down, alpha in few_step_lora_pairs(lora_sd):
+        key = flat.get(name) if kind == "flat" else (name + ".weight" if name + ".weight" in sd else None)
+        if key is None:
+            if strict:
+                raise KeyError(f"few-step LoRA module {name!r} not found in the UNet state dict")
+            continue
+        w = sd[key]
+        u, d = up.to(torch.float32), down.to(torch.float32)
+        rank = d.shape[0]
+        scale = lora_scale * (float(alpha) / rank if alpha is not None else 1.0)
+        delta = (u.reshape(u.shape[0], -1) @ d.reshape(d.shape[0], -1)).reshape(w.shape)
+        sd[key] = (w.to(torch.float32) + scale * delta).to(w.dtype)
+        touched.append(key)
+    if strict and not touched:
+        raise ValueError("the few-step LoRA touched no UNet weight: unknown key layout")
+    return touched
+
+
 def build_state_dict(base_sd: Dict[str, torch.Tensor], cfg: UNetConfig, dreambooth: Optional[Dict[str, torch.Tensor]] = None,
-                     loras: Optional[List[Tuple[Dict[str, torch.Tensor], float]]] = None) -> Dict[str, torch.Tensor]:
-    """The reference's ingestion order (wrapper.py:417-466 / convert.py:11-134) on state dicts: base Live2Diff weights,
-    DreamBooth spatial weights over them (`load_state_dict(strict=False)`: motion modules keep the base weights), then each
-    LoRA merged at its strength.  The result is what `HipStreamingUNet(state_dict, ...)` packs and `save_packed` caches
+                     loras: Optional[List[Tuple[Dict[str, torch.Tensor], float]]] = None,
+                     motion_ckpt: Optional[Dict] = None, few_step_lora: Optional[Dict[str, torch.Tensor]] = None,
+                     strict_lora: bool = True) -> Dict[str, torch.Tensor]:
+    """The reference's ingestion order on state dicts, from raw checkpoints alone:
+      1. base SD-1.5 UNet weights inflated into the streaming topology (`from_pretrained_2d`: the caller's `base_sd`);
+      2. `motion_ckpt` = live2diff.ckpt over them (pipeline_animatediff_depth.py:281-290, `merge_motion_checkpoint`);
+      3. DreamBooth spatial weights (`load_third_party_checkpoints`, :303; `load_state_dict(strict=False)`: motion modules
+         keep their weights);
+      4. the few-step (LCM) LoRA at scale 1 (wrapper.py:451-452) -- before the PE tables are projected (:454-459), i.e. before
+         packing;
+      5. each user LoRA at its strength (wrapper.py:461-466; kohya files, convert.py:72-88).
+    A LoRA that resolves against NO weight raises (strict_lora=False: warns) instead of silently merging nothing.
+    The result is what `HipStreamingUNet(state_dict, ...)` packs and `save_packed` caches
     (cache name: `HipStreamingUNet.packed_cache_name`)."""
     sd = dict(base_sd)
+    if motion_ckpt is not None:
+        merge_motion_checkpoint(sd, motion_ckpt)
     if dreambooth is not None:
         conv = convert_ldm_unet_checkpoint(dreambooth, cfg)
         unknown = [k for k in conv if k not in sd]
@@ -141,8 +229,18 @@ def build_state_dict(base_sd: Dict[str, torch.Tensor], cfg: UNetConfig, dreamboo
             if tuple(v.shape) != tuple(sd[k].shape):
                 raise ValueError(f"{k}: DreamBooth tensor {tuple(v.shape)} != UNet parameter {tuple(sd[k].shape)}")
             sd[k] = v.to(sd[k].dtype)
+    if few_step_lora is not None:
+        merge_few_step_lora(sd, few_step_lora, 1.0, strict=strict_lora)
     for lora_sd, alpha in (loras or []):
-        merge_lora(sd, lora_sd, alpha)
+        touched = merge_lora(sd, lora_sd, alpha)
+        n_pairs = sum(1 for _ in lora_pairs(lora_sd))
+        if len(touched) < n_pairs or not touched:
+            msg = (f"LoRA merge resolved {len(touched)} of {n_pairs} UNet pairs against the state dict (a peft / diffusers-"
+                   "keyed file, or another topology?)")
+            if strict_lora:
+                raise KeyError(msg)
+            import warnings
+            warnings.warn(msg)
     return sd
 
 

@@ -848,7 +848,10 @@ int l2d_launch_igemm(const l2d_op *op, hipStream_t s) {
     if (a.gn1) {
         // (tile 0 = auto is resolved below: require the larger one; the two-launch split-K reduction works on 64x64 tiles)
         const int tm = ((a.splitk > 1 && !a.cnt) || tile == 2) ? 64 : 128;
-        const bool vec_ok = a.epl && (a.Nout % 8) == 0 && (a.ldo % 8) == 0 && !(a.res && (a.ldr % 8)) && a.epi != 1;
+        // (the kernel's LDS-staged epilogue -- the only one that accumulates statistics -- also needs 16-byte aligned out /
+        // residual pointers: a misaligned sub-view would silently take the direct epilogue and leave the accumulators zero)
+        const bool vec_ok = a.epl && (a.Nout % 8) == 0 && (a.ldo % 8) == 0 && !(a.res && (a.ldr % 8)) && a.epi != 1 &&
+                            (((unsigned long long)a.out) & 15) == 0 && (((unsigned long long)a.res) & 15) == 0;
         if (a.gnT <= 0 || a.gnG <= 0 || a.gnG > 32 || a.cpg1 <= 0 || (a.gn2 && a.cpg2 <= 0) || batch != 1 ||
             ((a.cpg1 | a.choff1) & 1) || (a.gn2 && ((a.cpg2 | a.choff2) & 1)) ||
             (a.gnT % tm) != 0 || ((a.splitk == 1 || a.cnt) && !vec_ok) || (a.M % a.gnT) != 0) {

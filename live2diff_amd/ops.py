@@ -88,7 +88,8 @@ def igemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -
     tm = 64 if ((splitk > 1 and not fused) or tile == 2) else 128
     Nout, ldo, ldr, epi, batch = op.i[14], op.i[15], op.i[16], op.i[19], max(1, op.i[20])
     direct = (op.i[22] >> 5) & 1
-    vec_ok = (not direct) and Nout % 8 == 0 and ldo % 8 == 0 and not (op.p[5] and ldr % 8) and epi != 1
+    vec_ok = ((not direct) and Nout % 8 == 0 and ldo % 8 == 0 and not (op.p[5] and ldr % 8) and epi != 1
+              and (op.p[6] or 0) % 16 == 0 and (op.p[5] or 0) % 16 == 0)     # 16-byte aligned out / residual (sub-views)
     if T % tm or batch != 1 or ((splitk == 1 or fused) and not vec_ok) or op.i[13] % T or G > 32:
         return False
     if op.p[9] and (op.i[24], op.i[25]) != (T, G):

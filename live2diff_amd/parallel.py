@@ -16,12 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None):
-    """Initialise from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns (rank, world, local)."""
+def init_distributed(backend: Optional[str] = None, force: bool = False):
+    """Initialise from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns (rank, world, local).
+    `force`: create the process group even for world size 1 (exercises the backend's API surface on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -33,7 +34,8 @@ def init_distributed(backend: Optional[str] = None):
 
 
 def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Tensor]], device, dtype=torch.float16,
-                         src: int = 0, bucket_elems: int = 512 * 1024 * 1024, algo: str = "scatter_allgather") -> Dict[str, torch.Tensor]:
+                         src: int = 0, bucket_elems: int = 512 * 1024 * 1024, algo: str = "scatter_allgather",
+                         force_collectives: bool = False) -> Dict[str, torch.Tensor]:
     """Rank `src` holds `sd`; every rank returns a full copy on `device`.
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a root-sourced broadcast is bound by what ONE link / a
@@ -42,11 +44,13 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
         1. scatter     rank `src` sends shard g (1/G of the bucket) to peer g -- G-1 different shards leave the root over
                        G-1 different links at once, each link carries 1/G of the bytes;
         2. all-gather  every rank re-sends its shard to all peers (all links of all GPUs busy).
-    `algo="broadcast"` keeps the plain bucketed `dist.broadcast` for comparison.  A checksum (fp64 sum of every bucket) is
-    all-reduced with MIN and MAX, which must agree, to verify the replicas."""
+    `algo="broadcast"` keeps the plain bucketed `dist.broadcast` for comparison.  A position-sensitive checksum (fp64,
+    every element weighted by a function of its index in the bucket, so shards gathered in the wrong rank order change it)
+    is all-reduced with MIN and MAX, which must agree, to verify the replicas.  `force_collectives` runs the collectives
+    even for world size 1 (a one-rank process group: the RCCL calls execute on a single-GPU box)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and not (force_collectives and dist.is_initialized()):
         return {k: sd[k].to(device=device, dtype=dtype) for k in spec}
     keys = list(spec)
     out: Dict[str, torch.Tensor] = {}
@@ -73,7 +77,7 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
             mine = torch.empty(shard, dtype=dtype, device=device)
             dist.scatter(mine, scatter_list=(list(flat.view(world, shard).unbind(0)) if rank == src else None), src=src)
             _all_gather_flat(flat, mine, world, shard)
-        checksum += flat[:n].double().sum()
+        checksum += _checksum(flat, n)
         off = 0
         for k in keys[i:j]:
             m = _numel(spec[k])
@@ -86,6 +90,20 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
     if not torch.equal(lo, hi):
         raise RuntimeError(f"weight broadcast checksum mismatch across ranks: {lo.item()} vs {hi.item()}")
     return out
+
+
+_CK_CHUNK = 1 << 24
+
+
+def _checksum(flat: torch.Tensor, n: int) -> torch.Tensor:
+    """sum_i flat[i] * (1 + (i mod 8191) / 8192) in fp64, in 16 M-element slices (no bucket-sized fp64 temporary).  The
+    weight depends on the element's position, so two equal-sized shards that swapped places change the sum."""
+    total = torch.zeros(1, dtype=torch.float64, device=flat.device)
+    for a in range(0, n, _CK_CHUNK):
+        b = min(n, a + _CK_CHUNK)
+        wgt = torch.arange(a, b, device=flat.device, dtype=torch.int64).remainder_(8191).to(torch.float64).mul_(1.0 / 8192.0).add_(1.0)
+        total += torch.sum(flat[a:b].to(torch.float64) * wgt, dtype=torch.float64)
+    return total
 
 
 def _all_gather_flat(flat: torch.Tensor, mine: torch.Tensor, world: int, shard: int):

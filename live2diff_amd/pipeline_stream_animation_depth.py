@@ -13,9 +13,10 @@ reference's public surface) but is organised around device
     keeps a second CPU-resident copy of all weights and moves it to the GPU for `prepare`, :315,338).
 
 VAE / text encoder / depth detector are the caller's objects (duck-typed exactly like the reference's
-`stream.vae`, `stream.text_encoder`, `stream.depth_detector` swap points); they are outside this path.  So is the
-near-duplicate frame filter (reference image_filter.py, SURVEY 2.1 #16 OUT OF SCOPE): `stream.similar_filter` is whatever
-object the caller attaches (`__call__(x) -> x | None`, `set_threshold`, `set_max_skip_frame`), e.g. the reference's own.
+`stream.vae`, `stream.text_encoder`, `stream.depth_detector` swap points); they are outside this path.  The
+near-duplicate frame gate (reference image_filter.py) defaults to this package's `frame_filter.SimilarImageFilter`;
+`stream.similar_filter` may be replaced by any object with `__call__(x) -> x | None`, `set_threshold`,
+`set_max_skip_frame`.
 """
 import time
 from typing import List, Literal, Optional, Tuple, Union
@@ -24,6 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .frame_filter import SimilarImageFilter
 from .scheduler import LCMSchedule
 
 WARMUP_FRAMES = 8
@@ -133,7 +135,7 @@ class StreamAnimateDiffusionDepth:
         self.do_add_noise = do_add_noise
         self.use_denoising_batch = use_denoising_batch
         self.similar_image_filter = False
-        self.similar_filter = getattr(pipe, "similar_filter", None)     # caller's object (out of scope here), duck-typed
+        self.similar_filter = getattr(pipe, "similar_filter", None) or SimilarImageFilter()   # duck-typed, replaceable
         self.prev_image_result = None
         self.image_processor = _ImageProcessor()
         self.text_encoder = getattr(pipe, "text_encoder", None)
@@ -179,9 +181,9 @@ class StreamAnimateDiffusionDepth:
                             safe_fusing=safe_fusing)
 
     def enable_similar_image_filter(self, threshold: float = 0.98, max_skip_frame: float = 10):
+        """reference :112-118"""
         if self.similar_filter is None:
-            raise RuntimeError("no frame filter attached: set `stream.similar_filter` (or `pipe.similar_filter`) to an object "
-                               "with __call__/set_threshold/set_max_skip_frame, e.g. the reference's SimilarImageFilter")
+            self.similar_filter = SimilarImageFilter()
         self.similar_image_filter = True
         self.similar_filter.set_threshold(threshold)
         self.similar_filter.set_max_skip_frame(max_skip_frame)
@@ -294,6 +296,9 @@ class StreamAnimateDiffusionDepth:
         emb = self.pipe._encode_prompt(prompt=prompt, device=self.device, num_videos_per_prompt=1,
                                        do_classifier_free_guidance=False)[0]
         self.prompt_embeds = emb.to(device=self.device, dtype=self.dtype).repeat(self.batch_size, 1, 1)
+        inval = getattr(self.unet, "invalidate_text_cache", None)
+        if inval is not None:             # explicit: never rely on tensor identity alone for a prompt change
+            inval()
         ds = getattr(self, "_device_step", None)
         if ds is not None:                # the device step reads the prompt from the plan's static input buffer
             ds.set_prompt(self.prompt_embeds)

@@ -95,7 +95,7 @@ class _Act:
 class HipStreamingUNet:
     def __init__(self, state_dict, cfg: UNetConfig, height: int, width: int,
                  denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
-                 tattn_variant: int = 0, text_len: int = 77):
+                 tattn_variant: int = 0, text_len: int = 77, fresh_output: bool = False):
         """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names; it may also be the
         path of a packed-weight file written by `save_packed`."""
         assert cfg.num_heads == 8 and cfg.temporal_heads == 8
@@ -104,6 +104,8 @@ class HipStreamingUNet:
         self.device = torch.device(device)
         self.F = cfg.sink_size if warmup_frames is None else warmup_frames
         self.use_graph = use_graph
+        self.fresh_output = fresh_output   # True: return a private copy of the prediction (the reference's PyTorch path returns a
+        #                                    fresh tensor); False (default): a view of the static output buffer, like a TensorRT binding
         self.tattn_variant = tattn_variant
         self.igemm_splitk_off = False       # tuning knob: disable split-K schedules
         self.cond_cache = os.environ.get("L2D_COND_CACHE", "1") != "0"   # 0: re-run the conditioning launches every call
@@ -738,6 +740,9 @@ class HipStreamingUNet:
         st.in_pe_idx.copy_(pe_idx)
         st.in_upd.copy_(update_idx)
         self._run(st)
+        if self.fresh_output:
+            out = st.out_sample.clone().view(N, cfg.out_channels, 1, self.h, self.w)
+            return UNetOutput(out, kv_cache) if return_dict else (out, kv_cache)
         out = st.out_sample.view(N, cfg.out_channels, 1, self.h, self.w)    # a view of the plan's static output buffer (like
         if not return_dict:                                                  # the TensorRT engine's output binding): the next call overwrites it
             return (out, kv_cache)

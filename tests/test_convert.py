@@ -95,3 +95,77 @@ def test_build_state_dict_feeds_the_packed_cache(tmp_path):
         kk = next(iter(bad))
         bad[kk] = torch.zeros(3, 3)
         build_state_dict(base, cfg, dreambooth=bad)
+
+
+def test_raw_checkpoint_ingestion_motion_ckpt_and_few_step_lora():
+    """F4 remainder: the live2diff.ckpt merge (reference pipeline_animatediff_depth.py:281-290) and the few-step (LCM) LoRA
+    fuse that every run applies before the PE tables are projected (wrapper.py:451-459), on plain state dicts.  The fuse
+    arithmetic is diffusers 0.25.0's (not under /root/reference: parity unpinned) -- checked against the formula."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.convert import build_state_dict, merge_few_step_lora, merge_lora, merge_motion_checkpoint
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    base = random_state_dict(cfg, dtype=torch.float16)
+    # --- motion checkpoint: DDP-prefixed keys, a `grid` buffer to drop, wrapped in {"state_dict": ...}
+    mkeys = [k for k in base if "motion_modules" in k][:40]
+    ck = {"global_step": 7, "state_dict": {"module." + k: (base[k].float() + 1.0).half() for k in mkeys}}
+    ck["state_dict"]["module.flow_conv_in.grid"] = torch.zeros(3)
+    sd = dict(base)
+    assert sorted(merge_motion_checkpoint(sd, ck)) == sorted(mkeys)
+    assert all(torch.equal(sd[k], (base[k].float() + 1.0).half()) for k in mkeys)
+    assert all(torch.equal(sd[k], base[k]) for k in base if k not in mkeys)
+    with pytest.raises(KeyError):
+        merge_motion_checkpoint(dict(base), {"module.not_a_parameter.weight": torch.zeros(1)})
+    # --- few-step LoRA, three key layouts of the same pairs: kohya (+alpha), diffusers `lora.down`, peft `lora_A`
+    lin = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    out = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0"
+    conv = "down_blocks.0.resnets.0.conv1"
+    mot = next(k[: -len(".weight")] for k in base if "motion_modules" in k and k.endswith("attention_blocks.0.to_q.weight"))
+    g = torch.Generator().manual_seed(5)
+    pairs = {}
+    for m in (lin, out, conv, mot):
+        w = base[m + ".weight"]
+        r = 4
+        down = torch.randn(r, w.shape[1], *w.shape[2:], generator=g) * 0.05
+        up = torch.randn(w.shape[0], r, *([1] * (w.dim() - 2)), generator=g) * 0.05
+        pairs[m] = (up, down)
+    alpha = 2.0
+    want = {m + ".weight": (base[m + ".weight"].float() + 1.0 * (alpha / 4) *
+                            (u.reshape(u.shape[0], -1) @ d.reshape(4, -1)).reshape(base[m + ".weight"].shape)).half()
+            for m, (u, d) in pairs.items()}
+    kohya, dfs, peft = {}, {}, {}
+    for m, (u, d) in pairs.items():
+        f = "lora_unet_" + m.replace(".", "_")
+        kohya[f + ".lora_down.weight"], kohya[f + ".lora_up.weight"], kohya[f + ".alpha"] = d, u, torch.tensor(alpha)
+        dfs["unet." + m + ".lora.down.weight"], dfs["unet." + m + ".lora.up.weight"] = d, u * (alpha / 4)
+        peft["unet." + m + ".lora_A.weight"], peft["unet." + m + ".lora_B.weight"] = d, u * (alpha / 4)
+    kohya["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight"] = torch.zeros(4, 8)       # not the UNet's business
+    kohya["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"] = torch.zeros(8, 4)
+    for name, lora in (("kohya", kohya), ("diffusers", dfs), ("peft", peft)):
+        sd = dict(base)
+        touched = merge_few_step_lora(sd, lora)
+        assert sorted(touched) == sorted(want), name
+        for k in base:
+            assert torch.equal(sd[k], want.get(k, base[k])), (name, k)
+    # attention-processor form of the linear pair
+    proc = {"unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora.down.weight": pairs[lin][1],
+            "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora.up.weight": pairs[lin][0] * (alpha / 4)}
+    sd = dict(base)
+    assert merge_few_step_lora(sd, proc) == [lin + ".weight"] and torch.equal(sd[lin + ".weight"], want[lin + ".weight"])
+    with pytest.raises((KeyError, ValueError)):
+        merge_few_step_lora(dict(base), {"unet.nope.lora.down.weight": torch.zeros(4, 8), "unet.nope.lora.up.weight": torch.zeros(8, 4)})
+    # --- the whole order from raw checkpoints; the motion-module pair is merged BEFORE packing projects the PE tables
+    sd = build_state_dict(base, cfg, motion_ckpt=ck, few_step_lora=kohya)
+    k = mot + ".weight"
+    assert k in ["%s" % x for x in sd] and not torch.equal(sd[k], base[k])
+    # --- a LoRA that resolves against nothing is an error, not a silent no-op; and conv_in merges never touch the caller's tensors
+    with pytest.raises(KeyError):
+        build_state_dict(base, cfg, loras=[({"lora_unet_down_blocks_9_foo.lora_down.weight": torch.zeros(4, 8),
+                                             "lora_unet_down_blocks_9_foo.lora_up.weight": torch.zeros(8, 4)}, 1.0)])
+    b32 = {k: v.float() for k, v in base.items()}
+    keep = b32["conv_in.weight"].clone()
+    ci = {"lora_unet_conv_in.lora_down.weight": torch.ones(2, 4, 3, 3) * 0.1, "lora_unet_conv_in.lora_up.weight": torch.ones(b32["conv_in.weight"].shape[0], 2, 1, 1)}
+    s1 = build_state_dict(b32, cfg, loras=[(ci, 1.0)])
+    s2 = build_state_dict(b32, cfg, loras=[(ci, 1.0)])
+    assert torch.equal(b32["conv_in.weight"], keep) and torch.equal(s1["conv_in.weight"], s2["conv_in.weight"])
+    assert not torch.equal(s1["conv_in.weight"], keep)

@@ -184,12 +184,13 @@ def test_sd15_width_single_step(golden, sd15_weights):
 
 
 @pytest.mark.parametrize("name,h,w,N,L,S,prefill,frames", [
+    ("cfg-1 parameters: 256x256 aspect, N = 1 denoise step, L = 4 sink + 8 rolling", 16, 16, 1, 12, 4, 9, 4),
     ("cfg-3 parameters: 768x512 aspect (2:3), N=2, L = 8 sink + 16 rolling", 16, 24, 2, 24, 8, 21, 4),
     ("cfg-4 parameters: N = 4 denoise steps, L = 16", 16, 16, 4, 16, 8, 6, 4),
     ("cfg-5 parameters: 1024x576 aspect (16:9), N=2, L = 8 sink + 32 rolling", 8, 16, 2, 40, 8, 37, 4),
 ])
 def test_sd15_width_other_baseline_configs(golden, sd15_weights, name, h, w, N, L, S, prefill, frames):
-    """The window / step / aspect parameters of BASELINE.json configs 3, 4, 5 at the REAL SD-1.5 widths (C = 320 / 640 /
+    """The window / step / aspect parameters of BASELINE.json configs 1, 3, 4, 5 at the REAL SD-1.5 widths (C = 320 / 640 /
     1280, d = 40 / 80 / 160) on a reduced latent, against the oracle.  The streams start from random pre-filled caches with
     the ring buffer advanced `prefill` frames on the host, so the 4 frames run here straddle the point where the rolling
     window fills up and starts to rotate (cfg-4: while rows are still at different fill levels); the warm-up pass at these

@@ -1,11 +1,14 @@
 """CPU tests (-m "not gpu"): host-side logic against the reference goldens, and the C-ABI library surface."""
 import ctypes
+import sys
 import os
 import re
 
 import numpy as np
 import pytest
 import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -407,3 +410,24 @@ def test_float_assisted_division_is_exact():
             assert np.array_equal(divf(nn, np.full_like(nn, dd)), nn // dd), dd
         top = np.arange((1 << 24) - 100_000, 1 << 24, dtype=np.int64)
         assert np.array_equal(divf(top, np.full_like(top, dd)), top // dd), dd
+
+
+def test_frame_filter_matches_reference_trace():
+    """`frame_filter.SimilarImageFilter` (the default behind enable_similar_image_filter) against pass / drop decisions
+    captured from the reference's own class (tests/golden/gen_golden_filter.py) on the same seeded frames and draws."""
+    import json
+    import random
+
+    from live2diff_amd.frame_filter import SimilarImageFilter
+    sys.path.insert(0, GOLDEN)
+    from gen_golden_filter import frame_sequence
+    with open(os.path.join(GOLDEN, "frame_filter.json")) as fh:
+        want = json.load(fh)
+    assert any(0 < sum(v) < len(v) for v in want.values())          # the trace exercises both outcomes
+    for key, dec in want.items():
+        thr, ms = key.split(",")
+        random.seed(4321)
+        f = SimilarImageFilter()
+        f.set_threshold(float(thr)); f.set_max_skip_frame(float(ms))
+        got = [0 if f(x) is None else 1 for x in frame_sequence()]
+        assert got == dec, key

@@ -34,7 +34,12 @@ WORKER = textwrap.dedent("""
     parallel.barrier()
     assert parallel.max_over_ranks(float(rank + 1)) == 2.0
     assert parallel.sum_over_ranks(float(rb[2][0])) == float((8 + 3) + (8 + 4))
-    print("rank", rank, "ok")
+    # the checksum is position sensitive: two equal-sized shards in the wrong order must change it
+    t = torch.arange(64, dtype=torch.float16)
+    assert not torch.equal(parallel._checksum(t, 64), parallel._checksum(torch.cat([t[32:], t[:32]]), 64))
+    parallel.barrier()
+    print("rank", rank, "ok", flush=True)
+    torch.distributed.destroy_process_group()
 """)
 
 
