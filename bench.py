@@ -48,6 +48,9 @@ def op_work(op, kinds):
         flops = 2.0 * M * nreal * taps * (C1 + C2) * batch
         byts = 2.0 * batch * (M * (C1 + C2) + nreal * taps * (C1 + C2) + M * (Nout // 2 if i[19] == 1 else Nout))
         return flops, byts
+    if k == kinds.OP_ROWGEMM:
+        M, K, Nout = i[0], i[1], i[2]
+        return 2.0 * M * Nout * K, 2.0 * (M * K + Nout * K + M * (Nout // 2 if i[6] == 1 else Nout))
     if k == kinds.OP_FLASH_ATTN:
         B, H, d, Tq, Tk = i[0], i[1], i[2], i[3], i[4]
         return 4.0 * B * H * Tq * Tk * d, 2.0 * B * H * d * (2 * Tq + 2 * Tk)
@@ -68,7 +71,7 @@ def op_work(op, kinds):
 
 KIND_NAMES = {1: "igemm_kernel", 2: "gn_stats_kernel", 3: "gn_apply_kernel", 4: "layernorm_kernel", 5: "flash_attn_kernel",
               6: "tattn_stream_kernel", 7: "tattn_warmup_kernel", 8: "skinny_linear_kernel", 9: "timestep_embed_kernel",
-              10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy"}
+              10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy", 23: "rowgemm_kernel"}
 
 
 def per_kernel_breakdown(unet, reps=5):
@@ -127,6 +130,9 @@ def op_dims(op, kinds):
     if op.kind == kinds.OP_IGEMM:
         return (f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} Kp{i[0] * i[5]} s{i[11]} u{i[12]} e{i[19]} "
                 f"b{max(1, i[20])} S{max(1, i[21])} t{i[22] & 15} v{i[23]} o{i[22] >> 4}")
+    if op.kind == kinds.OP_ROWGEMM:
+        i = op.i
+        return f"M{i[0]} N{i[2]} K{i[1]} e{i[6]} p{i[7]} w{i[12]} t{i[13]} m{i[14]} tr{i[15]}"
     if op.kind == kinds.OP_FLASH_ATTN:
         return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
     if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 2
+#define L2D_ABI_VERSION 3
 
 enum {
     L2D_OK = 0,
@@ -143,6 +143,23 @@ enum {
  * L2D_OP_RESAMPLE_NHWC  channels-last p0 in [B,H,W,C] -> p1 out ; i0 B i1 H i2 W i3 C (% 8) i4 mode: 0 = 3x3 stride-2 max pool
  *   (SAME), 1 = stride-2 subsample, 2 = bilinear x2 upsample with align_corners=True
  * L2D_OP_EW        s = p0 (+ p1); p2 = s (if given); p3 = relu(s) (if given) ; l0 n halfs (% 8)
+ *
+ * L2D_OP_ROWGEMM   token-row GEMM for the transformer linear layers, with the normalisation in front of them fused:
+ *                out[m][n] = epi( sum_k T(x)[m][k] * W[n][k] ),  K % 64 == 0, K <= 2048  (rowgemm.hip; reference: nn.LayerNorm /
+ *                GroupNorm + nn.Linear, attention.py:57-62,89,102-110,173-205; motion_module.py:181-182,207,273-279,355-361)
+ *   p0 x [M][ldx] half   p1 w half, packed in MFMA-fragment order [Nout/32][K/16][64 lanes][8] (ops.pack_rowgemm; GEGLU: rows
+ *   permuted so that a 32-row tile holds 8 value / 8 gate / 8 value / 8 gate rows of 16 output channels)
+ *   p2 bias float [Nout] (packed order) or 0   p3 residual [M][ldr] half or 0   p4 out [M][ldo] half
+ *   p5 gamma / p6 beta half [K] of the prologue norm   p7 prologue 2: int64 [samples][G][2] fixed-point statistics of x
+ *   p8 outT half: output of the LAST i15 weight tiles, stored transposed [sample][channel][ldt] (V^T for the flash kernel)
+ *   p9 / p10, i24..i29: GroupNorm statistics of the output for up to two consumers, exactly as L2D_OP_IGEMM
+ *   i0 M i1 K i2 Nout (packed rows, % 32) i3 ldx i4 ldo i5 ldr i6 epi (0 none, 1 GEGLU: Nout / 2 output columns)
+ *   i7 prologue (0 none, 1 LayerNorm over K, 2 GroupNorm apply) i8 activation after prologue 2 (0 none, 1 SiLU)
+ *   i9 T tokens per sample (prologue 2, transposed output: T % (32 MT) == 0) i10 G groups of prologue 2
+ *   i12 NW waves per block (1..10) i13 NT weight tiles per wave (1..4) i14 MT token tiles per block (1 | 2): a block
+ *   computes 32 MT tokens x 32 NW NT packed rows; (Nout / 32) % (NW NT) == 0 (ops.rowgemm_schedule)
+ *   i15 trailing weight tiles stored transposed to p8 (% (NW NT)) i16 ldt i17 block order (1 = weight-band major per XCD)
+ *   l0 elements between samples in p8 ; f0 eps of the prologue norm
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -167,6 +184,7 @@ enum {
     L2D_OP_STEM7X7 = 20,
     L2D_OP_RESAMPLE_NHWC = 21,
     L2D_OP_EW = 22,
+    L2D_OP_ROWGEMM = 23,
 };
 
 typedef struct l2d_op {
@@ -198,6 +216,10 @@ int l2d_graph_destroy(void *graph);
 
 /* timing helper for bench.py: hipEvent pair around `reps` runs of the ops on `stream`; returns ms. */
 int l2d_time_ops(const l2d_op *ops, int n, void *stream, int reps, float *ms_out);
+
+/* per-launch timing inside the op sequence (an event in front of every op, `reps` passes): us_out[n] = mean microseconds
+ * from op i's start marker to op i+1's (launch + the gap behind it).  For tools (schedule tuning, in-frame breakdowns). */
+int l2d_time_each(const l2d_op *ops, int n, void *stream, int reps, float *us_out);
 
 /* HBM copy microbenchmark (device-to-device float4 copy kernel), used to state the measured HBM peak
  * next to the datasheet number: copies `bytes` from src to dst `reps` times, returns GB/s (read+write). */

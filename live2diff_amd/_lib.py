@@ -19,8 +19,8 @@ OP_TATTN_STREAM, OP_TATTN_WARMUP, OP_SKINNY_LINEAR, OP_TIMESTEP_EMBED = 6, 7, 8,
 OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_LCM_STEP, OP_COPY = 10, 11, 12, 13
 OP_RING_UPDATE, OP_STREAM_SHIFT, OP_RANDN = 14, 15, 16
 OP_RESIZE_BILINEAR, OP_MINMAX, OP_DEPTH_NORM_RESIZE = 17, 18, 19
-OP_STEM7X7, OP_RESAMPLE_NHWC, OP_EW = 20, 21, 22
-ABI_VERSION = 2
+OP_STEM7X7, OP_RESAMPLE_NHWC, OP_EW, OP_ROWGEMM = 20, 21, 22, 23
+ABI_VERSION = 3
 
 
 class L2DError(RuntimeError):
@@ -54,6 +54,8 @@ def _load():
     lib.l2d_graph_destroy.argtypes = [ctypes.c_void_p]
     lib.l2d_time_ops.argtypes = [ctypes.POINTER(L2dOp), ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                  ctypes.POINTER(ctypes.c_float)]
+    lib.l2d_time_each.argtypes = [ctypes.POINTER(L2dOp), ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                  ctypes.POINTER(ctypes.c_float)]
     lib.l2d_copy_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.POINTER(ctypes.c_float)]
     lib.l2d_read_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -142,6 +144,14 @@ class OpList:
         ms = ctypes.c_float(0)
         check(lib.l2d_time_ops(self.array(), len(self._ops), ctypes.c_void_p(s), reps, ctypes.byref(ms)), "l2d_time_ops")
         return float(ms.value)
+
+
+    def time_each_us(self, reps=5, stream=None):
+        """mean in-sequence duration of every op (microseconds, incl. the gap to its successor): l2d_time_each"""
+        s = current_stream_ptr() if stream is None else stream
+        out = (ctypes.c_float * len(self._ops))()
+        check(lib.l2d_time_each(self.array(), len(self._ops), ctypes.c_void_p(s), reps, out), "l2d_time_each")
+        return list(out)
 
 
 class Graph:

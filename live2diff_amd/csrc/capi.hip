@@ -51,6 +51,7 @@ static int run_one(const l2d_op *op, hipStream_t s) {
         case L2D_OP_STEM7X7: return l2d_launch_stem7x7(op, s);
         case L2D_OP_RESAMPLE_NHWC: return l2d_launch_resample_nhwc(op, s);
         case L2D_OP_EW: return l2d_launch_ew(op, s);
+        case L2D_OP_ROWGEMM: return l2d_launch_rowgemm(op, s);
         case L2D_OP_COPY: {
             if (!op->p[0] || !op->p[1] || op->l[0] <= 0) {
                 l2d_set_error("copy(tag %d): invalid arguments", op->tag);
@@ -190,6 +191,36 @@ int l2d_time_ops(const l2d_op *ops, int n, void *stream, int reps, float *ms_out
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *ms_out = ms / (float)reps;
+    return rc;
+}
+
+// In-frame duration of every launch without a profiler: one hipEvent in front of each op and one behind the last, `reps`
+// passes; us_out[i] = mean time from op i's event to the next one (its launch incl. the gap to its successor), on `stream`.
+int l2d_time_each(const l2d_op *ops, int n, void *stream, int reps, float *us_out) {
+    if (!ops || n <= 0 || reps <= 0 || !us_out) {
+        l2d_set_error("time_each: invalid arguments");
+        return L2D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t *ev = new hipEvent_t[n + 1];
+    for (int i = 0; i <= n; ++i) hipEventCreate(&ev[i]);
+    for (int i = 0; i < n; ++i) us_out[i] = 0.f;
+    int rc = L2D_OK;
+    for (int r = 0; r < reps && rc == L2D_OK; ++r) {
+        for (int i = 0; i < n && rc == L2D_OK; ++i) {
+            hipEventRecord(ev[i], s);
+            rc = run_one(&ops[i], s);
+        }
+        hipEventRecord(ev[n], s);
+        hipEventSynchronize(ev[n]);
+        for (int i = 0; i < n && rc == L2D_OK; ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            us_out[i] += 1000.f * ms / (float)reps;
+        }
+    }
+    for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+    delete[] ev;
     return rc;
 }
 

@@ -42,6 +42,7 @@ int l2d_launch_depth_norm_resize(const l2d_op *op, hipStream_t s);
 int l2d_launch_stem7x7(const l2d_op *op, hipStream_t s);
 int l2d_launch_resample_nhwc(const l2d_op *op, hipStream_t s);
 int l2d_launch_ew(const l2d_op *op, hipStream_t s);
+int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s);
 
 #ifdef __HIPCC__
 // SiLU / GELU are evaluated per output element inside GEMM epilogues and the GroupNorm apply pass (tens of millions of
@@ -73,6 +74,27 @@ __device__ __forceinline__ float l2d_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// sum x in units of 2^-20, sum x^2 in units of 2^-12: integer adds commute, so the accumulated statistics do not depend on
+// the order in which blocks arrive (bit-repeatable frames), and |x| <= 65504 cannot overflow int64 at any size used here
+#define L2D_GN_S1_SCALE 1048576.0f
+#define L2D_GN_S2_SCALE 4096.0f
+
+// chs: per-channel (sum, sum of squares) of this block's tile, channels [c_lo, c_lo + nch) of the producing tensor, all of
+// sample `b`.  One thread per consumer group that overlaps the tile adds its channels and issues two integer atomics.
+__device__ __forceinline__ void l2d_gn_flush(unsigned long long *acc, int G, int cpg, int choff, int b, const float *chs1,
+                                               const float *chs2, int c_lo, int nch, int tid) {
+    if (!acc || nch <= 0) return;
+    const int first = choff + c_lo, last = first + nch - 1;
+    const int g0 = first / cpg, g = g0 + tid;
+    if (g > last / cpg || g >= G) return;
+    const int lo = max(g * cpg, first) - first, hi = min((g + 1) * cpg, last + 1) - first;
+    float s = 0.f, q = 0.f;
+    for (int c = lo; c < hi; ++c) { s += chs1[c]; q += chs2[c]; }
+    unsigned long long *dst = acc + ((long long)b * G + g) * 2;
+    atomicAdd(dst, (unsigned long long)__float2ll_rn(s * L2D_GN_S1_SCALE));
+    atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(q * L2D_GN_S2_SCALE));
+}
+
 __device__ __forceinline__ float l2d_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -96,27 +96,6 @@ __device__ __forceinline__ int l2d_divf(int n, int d, float inv) {
     return q;
 }
 
-// sum x in units of 2^-20, sum x^2 in units of 2^-12: integer adds commute, so the accumulated statistics do not depend on
-// the order in which blocks arrive (bit-repeatable frames), and |x| <= 65504 cannot overflow int64 at any size used here
-#define L2D_GN_S1_SCALE 1048576.0f
-#define L2D_GN_S2_SCALE 4096.0f
-
-// chs: per-channel (sum, sum of squares) of this block's tile, channels [c_lo, c_lo + nch) of the producing tensor, all of
-// sample `b`.  One thread per consumer group that overlaps the tile adds its channels and issues two integer atomics.
-__device__ __forceinline__ void igemm_gn_flush(unsigned long long *acc, int G, int cpg, int choff, int b, const float *chs1,
-                                               const float *chs2, int c_lo, int nch, int tid) {
-    if (!acc || nch <= 0) return;
-    const int first = choff + c_lo, last = first + nch - 1;
-    const int g0 = first / cpg, g = g0 + tid;
-    if (g > last / cpg || g >= G) return;
-    const int lo = max(g * cpg, first) - first, hi = min((g + 1) * cpg, last + 1) - first;
-    float s = 0.f, q = 0.f;
-    for (int c = lo; c < hi; ++c) { s += chs1[c]; q += chs2[c]; }
-    unsigned long long *dst = acc + ((long long)b * G + g) * 2;
-    atomicAdd(dst, (unsigned long long)__float2ll_rn(s * L2D_GN_S1_SCALE));
-    atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(q * L2D_GN_S2_SCALE));
-}
-
 // fused epilogue for 4 consecutive output channels n..n+3 of token m
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs &a, h16 *outp, const h16 *resp, int m, int n, f32x4 v) {
     const float *rb = a.rowbias ? a.rowbias + (long long)(m / a.rows_per_bias) * a.ldrb : nullptr;
@@ -664,8 +643,8 @@ __global__ __launch_bounds__(256, (TN == 128 && BK == 32) ? (NS == 2 ? 4 : 3) : 
             __syncthreads();
             // group sums in units of channel pairs (cpg, offsets and tile origin are all even)
             const int nch = min(tno, NoutO - n0o), bsmp = m0 / a.gnT;
-            igemm_gn_flush(a.gn1, a.gnG, a.cpg1 >> 1, a.choff1 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
-            igemm_gn_flush(a.gn2, a.gnG, a.cpg2 >> 1, a.choff2 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
+            l2d_gn_flush(a.gn1, a.gnG, a.cpg1 >> 1, a.choff1 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
+            l2d_gn_flush(a.gn2, a.gnG, a.cpg2 >> 1, a.choff2 >> 1, bsmp, chs1, chs2, n0o >> 1, nch >> 1, tid);
         }
         L2D_STAMP(7);                                   // block done (issue side)
         return;
@@ -753,8 +732,8 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(IGemmArgs a, int S)
         }
         __syncthreads();
         const int nch = min(64, a.Nout - tn * 64), bsmp = (tm * 64) / a.gnT;
-        igemm_gn_flush(a.gn1, a.gnG, a.cpg1, a.choff1, bsmp, chs[0], chs[1], tn * 64, nch, tid);
-        igemm_gn_flush(a.gn2, a.gnG, a.cpg2, a.choff2, bsmp, chs[0], chs[1], tn * 64, nch, tid);
+        l2d_gn_flush(a.gn1, a.gnG, a.cpg1, a.choff1, bsmp, chs[0], chs[1], tn * 64, nch, tid);
+        l2d_gn_flush(a.gn2, a.gnG, a.cpg2, a.choff2, bsmp, chs[0], chs[1], tn * 64, nch, tid);
     }
 }
 

@@ -66,6 +66,59 @@ def f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.float().contiguous()
 
 
+ROWGEMM_MAX_K = 2048
+
+
+def rowgemm_ok(nout: int, k: int) -> bool:
+    """Shapes the token-row GEMM (csrc/rowgemm.hip) takes: whole K resident in LDS, 32-row weight tiles."""
+    return k % 64 == 0 and 64 <= k <= ROWGEMM_MAX_K and nout % 32 == 0 and nout >= 32
+
+
+def rowgemm_geglu_perm(c4: int, device) -> torch.Tensor:
+    """Row order of a GEGLU projection [8C -> value | gate] for the 32x32 MFMA tile of rowgemm.hip: a 32-row tile holds 8
+    value rows, the 8 matching gate rows, the next 8 value rows and their gate rows, so that value and gate of one output
+    channel are the register groups (0, 1) / (2, 3) of the same lane."""
+    assert c4 % 16 == 0
+    t = torch.arange(c4 // 16, device=device)[:, None, None] * 16            # tile -> first output channel
+    h = torch.arange(2, device=device)[None, :, None] * 8                    # half of the tile
+    e = torch.arange(8, device=device)[None, None, :]
+    val = (t + h + e)                                                        # [tiles, 2, 8]
+    return torch.stack([val, val + c4], dim=2).reshape(-1)                   # [tiles, 2, (value, gate), 8]
+
+
+def pack_rowgemm(w: torch.Tensor, bias: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                 beta: Optional[torch.Tensor] = None, geglu: bool = False):
+    """[Nout, K] (or [Nout, K, 1, 1]) -> (weights in MFMA-fragment order, fp32 bias or None) for rowgemm.hip.
+
+    Fragment order: flat index (((t * S + s) * 64 + lane) * 8 + e) holds W[32 t + lane % 32][16 s + 8 (lane // 32) + e],
+    S = K / 16: the A operand of v_mfma_f32_32x32x16_f16 for weight tile t and k step s is one contiguous 1 KB block.
+    With `gamma` / `beta` (the affine parameters of the LayerNorm / GroupNorm in front of this layer) the affine map is
+    folded into the layer: W' = W diag(gamma), b' = b + W beta (computed in fp32 from the fp16 parameters), so the kernel's
+    prologue only normalises.  `geglu`: rows re-ordered by rowgemm_geglu_perm (bias likewise)."""
+    w = w.reshape(w.shape[0], -1).float()
+    n, k = w.shape
+    assert rowgemm_ok(n, k), (n, k)
+    b = None if bias is None else bias.float().clone()
+    if gamma is not None:
+        if beta is not None:
+            shift = w @ beta.float()
+            b = shift if b is None else b + shift
+        w = w * gamma.float()[None, :]
+    if geglu:
+        perm = rowgemm_geglu_perm(n // 2, w.device)
+        w = w[perm]
+        b = None if b is None else b[perm]
+    S = k // 16
+    packed = w.to(torch.float16).view(n // 32, 32, S, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    return packed, (None if b is None else b.contiguous())
+
+
+def unpack_rowgemm(packed: torch.Tensor, nout: int, k: int) -> torch.Tensor:
+    """inverse of the fragment permutation (tests)"""
+    S = k // 16
+    return packed.view(nout // 32, S, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(nout, k)
+
+
 # ----------------------------------------------------------------------------- op builders
 _ZERO_PAGES = {}
 
@@ -101,6 +154,135 @@ def igemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -
     op.i[24], op.i[25] = int(T), int(G)
     op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
     return True
+
+
+def rowgemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """The same request to a rowgemm op (its epilogue accumulates like igemm's LDS-staged one)."""
+    assert op.kind == _lib.OP_ROWGEMM
+    MT, ntr, epi = op.i[14], op.i[15], op.i[6]
+    if T % (32 * MT) or op.i[0] % T or ntr or epi == 1 or G > 32 or (cpg | choff) & 1:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
+
+
+def gn_target(op, acc_ptr: int, **kw) -> bool:
+    """Ask the GEMM op that produced a tensor to accumulate that tensor's GroupNorm statistics (igemm or rowgemm)."""
+    if op.kind == _lib.OP_IGEMM:
+        return igemm_gn_target(op, acc_ptr, **kw)
+    if op.kind == _lib.OP_ROWGEMM:
+        return rowgemm_gn_target(op, acc_ptr, **kw)
+    return False
+
+
+def _rowgemm_lds(K, NW, NT, MT, epi, pro, ntr, gn):
+    BM, BNp = 32 * MT, NW * NT * 32
+    BNo = BNp // 2 if epi == 1 else BNp
+    xs = BM * K * 2 + BM * 16 + ((2 * K + 64) * 4 if pro == 2 else 0)
+    os_ = BM * (BNo + 8) * 2 + (64 * NW * 32 + BNo * 4 if gn else 0)
+    if ntr:
+        os_ = max(os_, BNp * (BM + 8) * 2)
+    return max(xs, os_)
+
+
+def rowgemm_schedule(M: int, K: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0, gn: bool = True, T: int = 0):
+    """(NW, NT, MT) = waves per block, 32-row weight tiles per wave, 32-token tiles per block for a rowgemm launch.  A table
+    measured on MI355X (rowgemm_tuned.json, tools/rowgemm_sweep.py) when it holds the shape, else a small cost model:
+    per block one activation-tile load (dependent groups of 5 x 16 B per thread), then per wave NT * K * 64 bytes of weights
+    through a ring of ~16 KB (latency bound: ~20 GB/s per wave) or NT * MT * K / 16 MFMAs of 32 cycles, whichever is longer;
+    blocks run in rounds of 256 CUs x (blocks per CU by LDS and by 12 waves)."""
+    tiles = Nout // 32
+    force = os.environ.get("L2D_ROWGEMM_FORCE")        # "NW,NT,MT" (tools): applied where it divides the shape
+    if force:
+        nw, nt, mt = (int(v) for v in force.split(","))
+        if tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0 and nw <= (5 if nt >= 3 else 8) and not (mt == 2 and (nt > 2 or T % 64)) \
+                and _rowgemm_lds(K, nw, nt, mt, epi, pro, ntr, gn) <= 163840:
+            return nw, nt, mt
+    key = f"{M},{K},{Nout},{ntr},{epi}"
+    if key in _RG_TUNED and not (_RG_TUNED[key][2] == 2 and T % 64):
+        return tuple(_RG_TUNED[key])
+    cdiv = lambda a, b: (a + b - 1) // b
+    best, best_t = None, None
+    for mt in (1, 2):
+        if mt == 2 and (M < 4096 or T % 64):        # (a sample must be a whole number of token tiles for prologue 2 / V^T / statistics)
+            continue
+        for nt in (1, 2, 3, 4):
+            if mt == 2 and nt > 2:
+                continue
+            for nw in range(1, (5 if nt >= 3 else 8) + 1):
+                if tiles % (nw * nt) or (ntr // 32) % (nw * nt):
+                    continue
+                lds = _rowgemm_lds(K, nw, nt, mt, epi, pro, ntr, gn)
+                if lds > 163840:
+                    continue
+                bm = 32 * mt
+                blocks = cdiv(M, bm) * (tiles // (nw * nt))
+                bpc = max(1, min(163840 // lds, 12 // nw))
+                rounds = cdiv(blocks, 256 * bpc)
+                lpr = 16 if (64 * nw >= 16 * bm and K % 128 == 0) else 8
+                row_passes = cdiv(bm, 64 * nw // lpr)
+                t_x = 0.9 * row_passes * cdiv(K // (8 * lpr), 5) + (1.0 if pro == 2 else 0.0) + (0.5 if pro == 1 else 0.0)
+                t_w = nt * K * 64 / 20000.0
+                t_mm = nt * mt * (K / 16) * 32 * cdiv(nw * bpc, 4) / 2100.0
+                t = rounds * (t_x + max(t_w, t_mm) + 0.8)
+                if best_t is None or t < best_t - 1e-9 or (abs(t - best_t) <= 1e-9 and blocks < best[3]):
+                    best, best_t = (nw, nt, mt, blocks), t
+    assert best is not None, (M, K, Nout, ntr)
+    return best[:3]
+
+
+def _load_rg_tuned():
+    import json
+    path = os.path.join(os.path.dirname(__file__), "rowgemm_tuned.json")
+    if os.environ.get("L2D_ROWGEMM_NO_TABLE") or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)["shapes"]
+
+
+_RG_TUNED = _load_rg_tuned()
+
+
+def rowgemm(x, w, out, *, M, K, Nout, ldx, ldo, bias=None, res=None, ldr=0, epi=0, pro=0, eps=1e-5, T=0, G=0, gn_acc_ptr=None,
+            out_t=None, ntr=0, ldt=0, st=0, sched=None, order=None, x_off=0, out_off=0, res_off=0):
+    """Token-row GEMM (csrc/rowgemm.hip): out[m][n] = epi(sum_k norm(x)[m][k] W[n][k]).  `w` / `bias` come from pack_rowgemm
+    (affine of the norm folded in).  pro: 0 none, 1 LayerNorm over K, 2 GroupNorm from the fixed-point accumulators at
+    `gn_acc_ptr` (T tokens per sample, G groups).  The LAST `ntr` packed rows are stored transposed into out_t
+    [sample][row][ldt] (V^T).  sched = (NW, NT, MT) or None for rowgemm_schedule."""
+    op = L2dOp()
+    op.kind = _lib.OP_ROWGEMM
+    assert w.dtype == torch.float16 and w.numel() == Nout * K, (w.shape, Nout, K)
+    if sched is None:
+        sched = rowgemm_schedule(M, K, Nout, ntr, epi, pro, T=T)
+    NW, NT, MT = sched
+    op.p[0] = _ptr(_h(x)) + 2 * x_off
+    op.p[1] = _ptr(_h(w))
+    op.p[2] = _ptr(bias)
+    op.p[3] = (_ptr(_h(res)) + 2 * res_off) if res is not None else None
+    op.p[4] = (_ptr(_h(out)) + 2 * out_off) if out is not None else None
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Nout
+    if pro == 2:
+        assert gn_acc_ptr is not None
+        op.p[7] = int(gn_acc_ptr)
+    if ntr:
+        assert out_t is not None and ntr % 32 == 0
+        op.p[8] = _ptr(_h(out_t))
+    if order is None:
+        order = int(Nout * K > M * K)                  # weight-band major per XCD when the weights outweigh the activations
+    vals = [M, K, Nout, ldx, ldo, ldr, epi, pro, 0, T, G, 0, NW, NT, MT, ntr // 32, ldt, order]
+    for j, v in enumerate(vals):
+        op.i[j] = int(v)
+    op.l[0] = int(st)
+    op.f[0] = float(eps)
+    return op, (x, w, bias, res, out, out_t)
 
 
 def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, taps: int = 1):

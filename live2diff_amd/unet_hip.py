@@ -152,19 +152,39 @@ class HipStreamingUNet:
             W[name + ".w"] = ops.pack_conv3x3(g(name + ".weight"))
             W[name + ".b"] = ops.f32(g(name + ".bias"))
 
-        def lin(name, bias=True):
-            W[name + ".w"] = ops.pack_linear(g(name + ".weight"))
-            if bias:
-                W[name + ".b"] = ops.f32(g(name + ".bias"))
+        use_rg = os.environ.get("L2D_ROWGEMM", "1") != "0"     # A/B knob: 0 = every linear layer on igemm + separate norm launches
+
+        def rg_ok(wname):
+            n, k = sd[wname].shape[0], sd[wname][0].numel()
+            return use_rg and ops.rowgemm_ok(n, k)
+
+        def lin(name, bias=True, norm=None, old=False):
+            """Linear layer `name`; `norm` = the LayerNorm / GroupNorm whose output feeds it.  Token-row GEMM packing
+            (rowgemm.hip: fragment order, the norm's affine folded into weight and bias) when the shape allows, else -- and
+            with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
+            rg = rg_ok(name + ".weight")
+            if rg:
+                W[name + ".rw"], rb = ops.pack_rowgemm(g(name + ".weight"), g(name + ".bias") if bias else None,
+                                                       g(norm + ".weight") if norm else None, g(norm + ".bias") if norm else None)
+                if rb is not None:
+                    W[name + ".rb"] = rb
+            if not rg or old:
+                W[name + ".w"] = ops.pack_linear(g(name + ".weight"))
+                if bias:
+                    W[name + ".b"] = ops.f32(g(name + ".bias"))
 
         def norm(name):
             W[name + ".g"] = g(name + ".weight").to(torch.float16).contiguous()
             W[name + ".beta"] = g(name + ".bias").to(torch.float16).contiguous()
 
-        def ff(name):
-            w, b = ops.pack_geglu(g(name + ".net.0.proj.weight"), g(name + ".net.0.proj.bias"))
-            W[name + ".w1"], W[name + ".b1"] = w, b
-            lin(name + ".net.2")
+        def ff(name, norm, old=False):
+            pw, pb = name + ".net.0.proj.weight", name + ".net.0.proj.bias"
+            rg = rg_ok(pw) and sd[pw].shape[0] % 64 == 0
+            if rg:
+                W[name + ".rw1"], W[name + ".rb1"] = ops.pack_rowgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"), geglu=True)
+            if not rg or old:
+                W[name + ".w1"], W[name + ".b1"] = ops.pack_geglu(g(pw), g(pb))
+            lin(name + ".net.2", old=old)
 
         self.temb_names, self.temb_offsets = [], {}
         temb_w, temb_b = [], []
@@ -173,32 +193,47 @@ class HipStreamingUNet:
 
         def resnet(name):
             norm(name + ".norm1"); conv3(name + ".conv1"); norm(name + ".norm2"); conv3(name + ".conv2")
-            if (name + ".conv_shortcut.weight") in sd:
-                lin(name + ".conv_shortcut")
+            if (name + ".conv_shortcut.weight") in sd:        # (two-input concat GEMM: implicit-GEMM kernel)
+                W[name + ".conv_shortcut.w"] = ops.pack_linear(g(name + ".conv_shortcut.weight"))
+                W[name + ".conv_shortcut.b"] = ops.f32(g(name + ".conv_shortcut.bias"))
             self.temb_offsets[name] = sum(t.shape[0] for t in temb_w)
             temb_w.append(g(name + ".time_emb_proj.weight").to(torch.float16))
             temb_b.append(g(name + ".time_emb_proj.bias").float())
 
         def spatial(name):
-            norm(name + ".norm"); lin(name + ".proj_in"); lin(name + ".proj_out")
+            # the mid block sits at the lowest resolution, where T = h w / 64 need not be a multiple of the row GEMM's 32-token
+            # tile (its transposed V output and GroupNorm prologue need that): it keeps the implicit-GEMM packing as well
+            # (likewise any level of THIS instance where T % 32 != 0: small test latents; a packed-weight file written there
+            # holds both forms, one written at an SD resolution holds the second form for the mid block only)
+            lvl = cfg.num_levels - 1 if name.startswith("mid_block") else int(name.split(".")[1])
+            if name.startswith("up_blocks"):
+                lvl = cfg.num_levels - 1 - lvl
+            old = name.startswith("mid_block") or ((self.h >> lvl) * (self.w >> lvl)) % 32 != 0
             b = name + ".transformer_blocks.0"
+            norm(name + ".norm"); lin(name + ".proj_in", norm=name + ".norm", old=old); lin(name + ".proj_out", old=old)
             for n in ("norm1", "norm2", "norm3"):
                 norm(b + "." + n)
-            W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([g(b + ".attn1.to_q.weight"), g(b + ".attn1.to_k.weight")], 0))
-            W[b + ".attn1.v"] = ops.pack_linear(g(b + ".attn1.to_v.weight"))
-            lin(b + ".attn1.to_out.0")
-            lin(b + ".attn2.to_q", bias=False)
+            wq, wk, wv = (g(b + f".attn1.to_{c}.weight") for c in "qkv")
+            if rg_ok(b + ".attn1.to_q.weight"):
+                # q | k | v in one launch behind norm1 (V leaves transposed): rowgemm.hip
+                W[b + ".attn1.qkv.rw"], W[b + ".attn1.qkv.rb"] = ops.pack_rowgemm(
+                    torch.cat([wq, wk, wv], 0), None, g(b + ".norm1.weight"), g(b + ".norm1.bias"))
+            if not rg_ok(b + ".attn1.to_q.weight") or old:
+                W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([wq, wk], 0))
+                W[b + ".attn1.v"] = ops.pack_linear(wv)
+            lin(b + ".attn1.to_out.0", old=old)
+            lin(b + ".attn2.to_q", bias=False, norm=b + ".norm2", old=old)
             self.text_offsets[name] = sum(t.shape[0] for t in text_k)
             text_k.append(g(b + ".attn2.to_k.weight").to(torch.float16))
             text_v.append(g(b + ".attn2.to_v.weight").to(torch.float16))
-            lin(b + ".attn2.to_out.0")
-            ff(b + ".ff")
+            lin(b + ".attn2.to_out.0", old=old)
+            ff(b + ".ff", b + ".norm3", old=old)
 
         self.pe_tables = {}
 
         def motion(name, C):
             t = name + ".temporal_transformer"
-            norm(t + ".norm"); lin(t + ".proj_in"); lin(t + ".proj_out")
+            norm(t + ".norm"); lin(t + ".proj_in", norm=t + ".norm"); lin(t + ".proj_out")
             b = t + ".transformer_blocks.0"
             L = cfg.window_size
             if C not in self.pe_tables:
@@ -207,14 +242,18 @@ class HipStreamingUNet:
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
                 wq, wk, wv = g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")
-                W[a + ".qkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0))
+                if rg_ok(a + ".to_q.weight"):
+                    W[a + ".qkv.rw"], W[a + ".qkv.rb"] = ops.pack_rowgemm(
+                        torch.cat([wq, wk, wv], 0), None, g(b + f".norms.{j}.weight"), g(b + f".norms.{j}.bias"))
+                else:
+                    W[a + ".qkv"] = ops.pack_linear(torch.cat([wq, wk, wv], 0))
                 # pre-projected positional encodings (reference prepare_pe_buffer, stream_motion_module.py:79-97)
                 for nm, w_ in (("q_pe", wq), ("k_pe", wk), ("v_pe", wv)):
                     W[a + "." + nm] = (pe @ w_.float().t()).to(torch.float16).contiguous()
                 lin(a + ".to_out.0")
                 norm(b + f".norms.{j}")
             norm(b + ".ff_norm")
-            ff(b + ".ff")
+            ff(b + ".ff", b + ".ff_norm")
 
         conv3("conv_in")
         conv3("flow_conv_in.conv_in")
@@ -260,7 +299,7 @@ class HipStreamingUNet:
         return sum(t.numel() * t.element_size() for t in self.W.values())
 
     # ------------------------------------------------------------------ packed-weight cache
-    PACK_FORMAT = 1      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
+    PACK_FORMAT = 2      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
 
     def save_packed(self, path) -> None:
         """Write the packed weights (what `_pack_weights` produced from the reference-keyed state dict: merged
@@ -318,7 +357,8 @@ class HipStreamingUNet:
         # time_emb_proj, and the K / V^T text projections of all 16 cross-attention layers (frame-invariant).
         # They run when the conditioning changes (first frame, update_prompt, a new warm-up row), not every frame.
         cond_pl = _lib.OpList()
-        st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, cond_pl=cond_pl, cond_key=None, arena=ar, tattn_ops=[], warm=False)
+        st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, cond_pl=cond_pl, cond_key=None, arena=ar, tattn_ops=[], warm=False,
+                             ident={}, rg=os.environ.get("L2D_ROWGEMM", "1") != "0")
         cur = [cond_pl]
 
         def add(opk):
@@ -378,36 +418,52 @@ class HipStreamingUNet:
             if a is not None:
                 ar.release(a.buf)
 
-        def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None) -> _Act:
+        def ident_affine(C):
+            if C not in st.ident:
+                st.ident[C] = (torch.ones(C, dtype=torch.float16, device=dev), torch.zeros(C, dtype=torch.float16, device=dev))
+            return st.ident[C]
+
+        def gn_stats_target(x: _Act, x2: Optional[_Act], T, cpg):
+            """Ask the producers of x (and x2) to accumulate this GroupNorm's statistics; returns the accumulator pointer or
+            None (then nothing is left attached)."""
+            ins = [(x, 0)] + ([(x2, x.C)] if x2 is not None else [])
+            if not (st.gn_fuse and all(a_.producer is not None for a_, _ in ins) and st.gn_layers < st.gn_acc.shape[0]):
+                return None
+            acc_ptr = st.gn_acc.data_ptr() + st.gn_layers * B * G * 2 * 8
+            saved = [(a_.producer, [a_.producer.p[9], a_.producer.p[10]], list(a_.producer.i[24:30])) for a_, _ in ins]
+            if all(ops.gn_target(a_.producer, acc_ptr, T=T, G=G, cpg=cpg, choff=off) for a_, off in ins):
+                st.gn_layers += 1
+                return acc_ptr
+            for op_, ps, is_ in saved:                   # undo a half-attached layer
+                op_.p[9], op_.p[10] = ps
+                for j, v in enumerate(is_):
+                    op_.i[24 + j] = v
+            return None
+
+        def gn(x: _Act, name, eps, silu, x2: Optional[_Act] = None, affine: bool = True) -> _Act:
+            """affine=False: normalise only (gamma = 1, beta = 0): the consumer's packed weights carry the affine part."""
             T = x.H * x.W
             C2 = x2.C if x2 is not None else 0
             out = new_act(x.C + C2, x.H, x.W)
+            gam, bet = (W[name + ".g"], W[name + ".beta"]) if affine else ident_affine(x.C + C2)
             # Statistics from the producers: the igemm launches that wrote x (and x2) accumulate sum / sum of squares per
             # (sample, group of THIS GroupNorm) in their epilogues as fixed-point integer atomics -- no gn_stats launch, no
             # second pass over the tensor.  Falls back to the stats kernel when a producer cannot (tile straddles samples,
             # both of its target slots taken, direct epilogue forced).
             cpg = (x.C + C2) // G
-            ins = [(x, 0)] + ([(x2, x.C)] if x2 is not None else [])
-            if st.gn_fuse and all(a_.producer is not None for a_, _ in ins) and st.gn_layers < st.gn_acc.shape[0]:
-                acc_ptr = st.gn_acc.data_ptr() + st.gn_layers * B * G * 2 * 8
-                saved = [(a_.producer, [a_.producer.p[9], a_.producer.p[10]], list(a_.producer.i[24:30])) for a_, _ in ins]
-                if all(ops.igemm_gn_target(a_.producer, acc_ptr, T=T, G=G, cpg=cpg, choff=off) for a_, off in ins):
-                    st.gn_layers += 1
-                    add(ops.gn_apply(x.buf, None, W[name + ".g"], W[name + ".beta"], out.buf, eps=eps, silu=silu, B=B, T=T, C1=x.C,
-                                     ld1=x.C, G=G, nchunk=0, x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2,
-                                     acc_ptr=acc_ptr))
-                    return out
-                for op_, ps, is_ in saved:                   # undo a half-attached layer
-                    op_.p[9], op_.p[10] = ps
-                    for j, v in enumerate(is_):
-                        op_.i[24 + j] = v
+            acc_ptr = gn_stats_target(x, x2, T, cpg)
+            if acc_ptr is not None:
+                add(ops.gn_apply(x.buf, None, gam, bet, out.buf, eps=eps, silu=silu, B=B, T=T, C1=x.C,
+                                 ld1=x.C, G=G, nchunk=0, x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2,
+                                 acc_ptr=acc_ptr))
+                return out
             nchunk = max(1, min(int(os.environ.get("L2D_GN_NCHUNK", "64")), T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
                       ld2=C2)
             st.gn_stats_launches += 1
             add(ops.gn_stats(x.buf, partial, **kw))
-            add(ops.gn_apply(x.buf, partial, W[name + ".g"], W[name + ".beta"], out.buf, eps=eps, silu=silu, **kw))
+            add(ops.gn_apply(x.buf, partial, gam, bet, out.buf, eps=eps, silu=silu, **kw))
             ar.release(partial)
             return out
 
@@ -441,7 +497,25 @@ class HipStreamingUNet:
             return gemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=K, ldx1=ldx, CinP=wt.shape[1], ldo=ldo, bias=bias,
                         res=res, ldr=ldr, epi=epi, x2=x2, C2=C2, ldx2=ldx2, **kw)
 
-        def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None) -> _Act:
+        def rowlin(xbuf, M, K, wkey, bkey, outbuf, ldo, ldx=None, res=None, ldr=0, **kw):
+            """one token-row GEMM launch (rowgemm.hip) on weights packed by ops.pack_rowgemm"""
+            wt = W[wkey]
+            kw.setdefault("T", M // B)          # tokens per sample: 64-token tiles only when a sample is a whole number of them
+            return add(ops.rowgemm(xbuf, wt, outbuf, M=M, K=K, Nout=wt.numel() // K, ldx=(ldx or K), ldo=ldo, bias=W.get(bkey),
+                                   res=res, ldr=ldr, **kw))
+
+        def use_rg(key) -> bool:
+            return st.rg and (key + ".rw") in W
+
+        def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None, **kw) -> _Act:
+            """kw: pro / eps / T / G / gn_acc_ptr of a fused norm prologue (row GEMM only)"""
+            if x2 is None and wkey is None and use_rg(name):
+                nout = W[name + ".rw"].numel() // x.C
+                out = new_act(nout, x.H, x.W)
+                out.producer = rowlin(x.buf, B * x.H * x.W, x.C, name + ".rw", name + ".rb", out.buf, nout,
+                                      res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0), **kw)
+                return out
+            assert not kw
             wt = W[wkey or (name + ".w")]
             out = new_act(wt.shape[0], x.H, x.W)
             out.producer = linear_raw(x.buf, B * x.H * x.W, x.C, x.C, wt, out.buf, wt.shape[0], bias=(W[name + ".b"] if bias else None),
@@ -455,12 +529,45 @@ class HipStreamingUNet:
             add(ops.layernorm(x.buf, W[name + ".g"], W[name + ".beta"], out.buf, rows=B * x.H * x.W, C=x.C, ldx=x.C, ldo=x.C))
             return out
 
-        def geglu_ff(x: _Act, name, res: _Act) -> _Act:
+        def gn_linear(x: _Act, nname, eps, lname) -> _Act:
+            """GroupNorm -> Linear.  Row GEMM path: the normalisation is the GEMM's prologue (statistics from x's producers),
+            the affine part lives in the packed weights; if the statistics cannot come from the producers or a sample is not a
+            whole number of 32-token tiles, a normalise-only GroupNorm launch runs in front."""
+            if not use_rg(lname):
+                hn = gn(x, nname, eps, False)
+                y = linear(hn, lname)
+                free(hn)
+                return y
+            T = x.H * x.W
+            acc_ptr = gn_stats_target(x, None, T, x.C // G) if T % 32 == 0 else None
+            if acc_ptr is not None:
+                return linear(x, lname, pro=2, eps=eps, T=T, G=G, gn_acc_ptr=acc_ptr)
+            hn = gn(x, nname, eps, False, affine=False)
+            y = linear(hn, lname)
+            free(hn)
+            return y
+
+        def ln_rowlin(x: _Act, wkey, outbuf, ldo, **kw):
+            """LayerNorm -> Linear as one row GEMM launch (LayerNorm eps = 1e-5: nn.LayerNorm default, as ops.layernorm)"""
+            return rowlin(x.buf, B * x.H * x.W, x.C, wkey + ".rw", wkey + ".rb", outbuf, ldo, pro=1, eps=1e-5, **kw)
+
+        def geglu_ff(x: _Act, name, res: _Act, nname=None) -> _Act:
+            """x: the un-normalised input when `nname` names the LayerNorm to fuse (row GEMM), else the normalised one"""
+            if nname is not None:
+                c4 = W[name + ".rw1"].numel() // x.C // 2
+                hid = new_act(c4, x.H, x.W)
+                rowlin(x.buf, B * x.H * x.W, x.C, name + ".rw1", name + ".rb1", hid.buf, c4, pro=1, eps=1e-5, epi=1)
+                out = linear(hid, name + ".net.2", res=res)
+                free(hid)
+                return out
+            return geglu_ff_old(x, name, res)
+
+        def geglu_ff_old(x: _Act, name, res: _Act) -> _Act:
             w1 = W[name + ".w1"]
             c4 = w1.shape[0] // 2
             hid = new_act(c4, x.H, x.W)
             linear_raw(x.buf, B * x.H * x.W, x.C, x.C, w1, hid.buf, c4, bias=W[name + ".b1"], epi=1)
-            out = linear(hid, name + ".net.2", res=res)
+            out = linear(hid, name + ".net.2", res=res, **({} if use_rg(name + ".net.2") else dict(wkey=name + ".net.2.w")))
             free(hid)
             return out
 
@@ -483,31 +590,47 @@ class HipStreamingUNet:
         def spatial(x: _Act, name) -> _Act:
             T, C = x.H * x.W, x.C
             d = C // cfg.num_heads
-            hn = gn(x, name + ".norm", cfg.transformer_norm_eps, False)
-            y = linear(hn, name + ".proj_in")
-            free(hn)
             b = name + ".transformer_blocks.0"
-            # --- self attention
-            n1 = layernorm(y, b + ".norm1")
-            qk = ar.alloc(B * T * 2 * C)
-            linear_raw(n1.buf, B * T, C, C, W[b + ".attn1.qk"], qk, 2 * C)
+            rg = use_rg(b + ".attn1.qkv") and T % 32 == 0         # (else: the implicit-GEMM path with separate norm launches)
             ldvt = round_up(T, 8)
-            vt = ar.alloc(B * C * ldvt)
-            # V^T[b] = Wv . n1[b]^T : the same GEMM with operand roles swapped (tokens act as "channels")
-            wv = W[b + ".attn1.v"]
-            gemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
-                          sw=T * C, so=C * ldvt)
-            free(n1)
+            if rg:
+                y = gn_linear(x, name + ".norm", cfg.transformer_norm_eps, name + ".proj_in")
+                # --- self attention: norm1 -> q | k | V^T in ONE launch
+                qk = ar.alloc(B * T * 2 * C)
+                vt = ar.alloc(B * C * ldvt)
+                ln_rowlin(y, b + ".attn1.qkv", qk, 2 * C, T=T, out_t=vt, ntr=C, ldt=ldvt, st=C * ldvt)
+            else:
+                if (name + ".proj_in.w") not in W:
+                    raise ValueError(f"{name}: T = {T} tokens per sample is no multiple of 32 at this level and the packed weights "
+                                     "lack the implicit-GEMM form of this block (packed-weight file written at another "
+                                     "resolution): re-pack from the state dict at this resolution")
+                hn = gn(x, name + ".norm", cfg.transformer_norm_eps, False)
+                y = linear(hn, name + ".proj_in", wkey=name + ".proj_in.w")
+                free(hn)
+                n1 = layernorm(y, b + ".norm1")
+                qk = ar.alloc(B * T * 2 * C)
+                linear_raw(n1.buf, B * T, C, C, W[b + ".attn1.qk"], qk, 2 * C)
+                vt = ar.alloc(B * C * ldvt)
+                # V^T[b] = Wv . n1[b]^T : the same GEMM with operand roles swapped (tokens act as "channels")
+                wv = W[b + ".attn1.v"]
+                gemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
+                              sw=T * C, so=C * ldvt)
+                free(n1)
             ao = new_act(C, x.H, x.W)
             add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
                                ldo=C, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, k_off=C))
             ar.release(qk); ar.release(vt)
-            y2 = linear(ao, b + ".attn1.to_out.0", res=y)
+            lin = (lambda a_, nm, **k_: linear(a_, nm, **k_)) if rg else (lambda a_, nm, **k_: linear(a_, nm, wkey=nm + ".w", **k_))
+            y2 = lin(ao, b + ".attn1.to_out.0", res=y)
             free(ao); free(y)
             # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start)
-            n2 = layernorm(y2, b + ".norm2")
-            q2 = linear(n2, b + ".attn2.to_q", bias=False)
-            free(n2)
+            if rg:
+                q2 = new_act(C, x.H, x.W)
+                ln_rowlin(y2, b + ".attn2.to_q", q2.buf, C)
+            else:
+                n2 = layernorm(y2, b + ".norm2")
+                q2 = linear(n2, b + ".attn2.to_q", bias=False, wkey=b + ".attn2.to_q.w")
+                free(n2)
             off = self.text_offsets[name]
             ao = new_act(C, x.H, x.W)
             add(ops.flash_attn(q2.buf, st.text_k, st.text_vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=st.text_len,
@@ -515,28 +638,33 @@ class HipStreamingUNet:
                                sk=(TEXT_PAD * self.text_total if Bt > 1 else 0),
                                svt=(self.text_total * TEXT_PAD if Bt > 1 else 0), so=T * C, k_off=off, vt_off=off * TEXT_PAD))
             free(q2)
-            y3 = linear(ao, b + ".attn2.to_out.0", res=y2)
+            y3 = lin(ao, b + ".attn2.to_out.0", res=y2)
             free(ao); free(y2)
-            n3 = layernorm(y3, b + ".norm3")
-            y4 = geglu_ff(n3, b + ".ff", res=y3)
-            free(n3); free(y3)
-            out = linear(y4, name + ".proj_out", res=x)
+            if rg and (b + ".ff.rw1") in W:
+                y4 = geglu_ff(y3, b + ".ff", res=y3, nname=b + ".norm3")
+            else:
+                n3 = layernorm(y3, b + ".norm3")
+                y4 = geglu_ff_old(n3, b + ".ff", res=y3)
+                free(n3)
+            free(y3)
+            out = lin(y4, name + ".proj_out", res=x)
             free(y4)
             return out
 
         def motion(x: _Act, name, idx_base: int) -> _Act:
             T, C = x.H * x.W, x.C
             t = name + ".temporal_transformer"
-            hn = gn(x, t + ".norm", cfg.transformer_norm_eps, False)
-            y = linear(hn, t + ".proj_in")
-            free(hn)
+            y = gn_linear(x, t + ".norm", cfg.transformer_norm_eps, t + ".proj_in")
             b = t + ".transformer_blocks.0"
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
-                nrm = layernorm(y, b + f".norms.{j}")
                 qkv = ar.alloc(B * T * 3 * C)
-                linear_raw(nrm.buf, B * T, C, C, W[a + ".qkv"], qkv, 3 * C)
-                free(nrm)
+                if use_rg(a + ".qkv"):
+                    ln_rowlin(y, a + ".qkv", qkv, 3 * C)
+                else:
+                    nrm = layernorm(y, b + f".norms.{j}")
+                    linear_raw(nrm.buf, B * T, C, C, W[a + ".qkv"], qkv, 3 * C)
+                    free(nrm)
                 ao = new_act(C, x.H, x.W)
                 idx = idx_base + j
                 cache = kv_cache[idx]
@@ -552,9 +680,13 @@ class HipStreamingUNet:
                 y2 = linear(ao, a + ".to_out.0", res=y)
                 free(ao); free(y)
                 y = y2
-            nrm = layernorm(y, b + ".ff_norm")
-            y2 = geglu_ff(nrm, b + ".ff", res=y)
-            free(nrm); free(y)
+            if use_rg(b + ".ff") or (st.rg and (b + ".ff.rw1") in W):
+                y2 = geglu_ff(y, b + ".ff", res=y, nname=b + ".ff_norm")
+            else:
+                nrm = layernorm(y, b + ".ff_norm")
+                y2 = geglu_ff_old(nrm, b + ".ff", res=y)
+                free(nrm)
+            free(y)
             out = linear(y2, t + ".proj_out", res=x)
             free(y2)
             return out

@@ -97,7 +97,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib.l2d_abi_version() == 2
+    assert _lib.lib.l2d_abi_version() == _lib.ABI_VERSION == 3
     assert ctypes.sizeof(_lib.L2dOp) == 280          # ABI v2: 12 pointers + 32 ints + 4 int64 + 4 floats (+ kind, tag)
     # error path without a device: refused loudly, no fallback
     ops = (_lib.L2dOp * 1)()
@@ -142,7 +142,11 @@ def test_plan_builds_and_validates_without_gpu(dry_run, mode):
     summ = unet.plan_summary(mode)
     from live2diff_amd import _lib
     assert summ["kinds"][_lib.OP_TATTN_STREAM if mode == "stream" else _lib.OP_TATTN_WARMUP] == 40
-    assert summ["kinds"][_lib.OP_FLASH_ATTN] == 32 and summ["kinds"][_lib.OP_GN_APPLY] == 22 * 2 + 16 + 20 + 1
+    # every GroupNorm is either its own (apply) launch or the prologue of the row GEMM behind it (rowgemm.hip, prologue 2);
+    # no LayerNorm launch is left where the row GEMM applies (levels whose widths / token counts fit it)
+    n_gn_pro = sum(1 for op in st.pl._ops if op.kind == _lib.OP_ROWGEMM and op.i[7] == 2)
+    assert summ["kinds"][_lib.OP_FLASH_ATTN] == 32 and summ["kinds"][_lib.OP_GN_APPLY] + n_gn_pro == 22 * 2 + 16 + 20 + 1
+    assert n_gn_pro > 0 and summ["kinds"].get(_lib.OP_ROWGEMM, 0) > 100
     # a broken op is refused with a message naming it
     bad = st.pl[5]
     old = bad.i[15]
@@ -161,12 +165,15 @@ def test_plan_validates_sd15_shapes(dry_run):
     from live2diff_amd.weights import unet_param_spec
     cfg = sd15_config()
     sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    from live2diff_amd import _lib
     unet = HipStreamingUNet(sd, cfg, 64, 64, 2, device="cpu")
     del sd
     kv = unet.prepare_cache(2)
     st = unet._plan("stream", kv)
     st.pl.run(stream=0)
-    assert st.n_ops > 600
+    assert 400 < st.n_ops <= 500             # round 2: 643 (LayerNorm / GroupNorm launches folded into the row GEMMs, q | k | V^T fused)
+    kinds = unet.plan_summary()["kinds"]
+    assert _lib.OP_LAYERNORM not in kinds and kinds[_lib.OP_GN_APPLY] == 22 * 2 + 1      # resnet norms + conv_norm_out only
     assert abs(unet.weight_bytes() / 1e9 - 2.6) < 0.2
 
 
@@ -238,15 +245,19 @@ def test_packed_weight_cache_round_trip(dry_run, tmp_path):
     cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
     a = HipStreamingUNet(random_state_dict(cfg, dtype=torch.float16), cfg, 16, 16, 2, device="cpu")
     path = tmp_path / (HipStreamingUNet.packed_cache_name("sd15", "lcm", cfg.window_size, {"loras/style.safetensors": 0.8}) + ".safetensors")
-    assert path.name == f"sd15--lcm--style-0.8--L{cfg.window_size}--l2dpack1.safetensors"
+    assert path.name == f"sd15--lcm--style-0.8--L{cfg.window_size}--l2dpack2.safetensors"
     a.save_packed(path)
-    b = HipStreamingUNet(path, cfg, 8, 24, 3, device="cpu")           # other resolution / step count: same packed weights
+    b = HipStreamingUNet(path, cfg, 16, 32, 3, device="cpu")          # other resolution / step count: same packed weights
     assert set(a.W) == set(b.W) and all(torch.equal(a.W[k], b.W[k]) and a.W[k].dtype == b.W[k].dtype for k in a.W)
     assert a.temb_offsets == b.temb_offsets and a.text_offsets == b.text_offsets
     assert (a.temb_total, a.text_total, a.text_kp, a.n_map_blocks) == (b.temb_total, b.text_total, b.text_kp, b.n_map_blocks)
     b._plan("stream", b.prepare_cache(3)).pl.run(stream=0)             # validate-only
     with pytest.raises(ValueError):
         HipStreamingUNet(path, tiny_config(window_size=24, channels=(64, 128, 128, 128), cross_attention_dim=64), 16, 16, 2, device="cpu")
+    # a resolution whose token counts need the implicit-GEMM form of a level the file was not packed for: refused by name
+    c = HipStreamingUNet(path, cfg, 8, 24, 2, device="cpu")
+    with pytest.raises(ValueError, match="re-pack"):
+        c._plan("stream", c.prepare_cache(2))
 
 
 def test_plan_algorithmic_work_matches_survey(dry_run):
@@ -284,8 +295,10 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     assert abs(kv_bytes / 3.04e9 - 1) < 2e-3                           # 3.04 GB
     n, fl, by = tot[_lib.OP_TATTN_STREAM]
     assert n == 40 and abs(by - (kv_bytes + 2 * kv_bytes / cfg.window_size)) < 1e-6 * by   # K+V once + (row write, q, out) = 8 N T C bytes
-    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and tot[_lib.OP_IGEMM][0] == 380
-    assert abs(tot[_lib.OP_IGEMM][1] / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
+    # 380 GEMM launches in round 2; the 16 V^T projections now ride in the q | k | V^T row GEMMs
+    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and tot[_lib.OP_IGEMM][0] + tot[_lib.OP_ROWGEMM][0] == 380 - 16
+    assert abs((tot[_lib.OP_IGEMM][1] + tot[_lib.OP_ROWGEMM][1]) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
+    assert _lib.OP_LAYERNORM not in tot
 
 
 def test_pipeline_mirror_keeps_the_reference_api_surface():
