@@ -5,10 +5,15 @@ F2): `MidasDetector` = `DPTDepthModel(backbone="vitb_rn50_384", non_negative=Tru
 depth_utils.py:11-32), called from pipeline_stream_animation_depth.py:563 on a 384x384 image batch and returning inverse
 depth `[B, 384, 384]`.
 
-**Parity unpinned.**  The MiDaS repository (un-vendored git submodule `live2diff/MiDaS`, commit unknown) and the `timm` backbone it builds
-on (`vit_base_resnet50_384`) are neither under /root/reference nor installed here, and the reference holds no test vector
-for them.  What is restated is the published DPT-Hybrid architecture (Ranftl et al., "Vision Transformers for Dense
-Prediction", MiDaS v3 `DPTDepthModel(backbone="vitb_rn50_384", non_negative=True)`):
+**Pinned to an independent implementation, not to the reference's own code.**  The MiDaS repository (un-vendored git submodule
+`live2diff/MiDaS`, commit unknown) and the `timm` backbone it builds on (`vit_base_resnet50_384`) are neither under
+/root/reference nor installed here, and the reference holds no test vector for them.  What is restated is the published
+DPT-Hybrid architecture (Ranftl et al., "Vision Transformers for Dense Prediction", MiDaS v3 `DPTDepthModel(backbone=
+"vitb_rn50_384", non_negative=True)`), and it is CHECKED against a second, published implementation of that architecture:
+Hugging Face `transformers` `DPTForDepthEstimation(DPTConfig(is_hybrid=True))` (the class the converted MiDaS `dpt_hybrid`
+checkpoint runs on) on the same key-hashed weights -- 12 stage taps and the depth map at 128^2 and 384^2 agree to rel-L2
+<= 1e-4 in fp32 (tests/golden/gen_golden_midas.py -> midas_hf.npz, tests/test_midas_cpu.py).  Relative to the REFERENCE the
+row therefore stays "parity unpinned" (SURVEY 8c); relative to the published architecture it is pinned.
 
   backbone   ResNetV2-50 stem + stages (3, 4, 9 bottlenecks; weight-standardised convs with TF-"SAME" padding, GroupNorm(32))
              -> 1x1 projection to 768 -> 24 x 24 patch tokens + class token + position embedding -> 12 ViT-B blocks

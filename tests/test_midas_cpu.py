@@ -87,3 +87,41 @@ def test_oracle_forward_small_input_properties():
     assert taps["l4"].shape == (2, 768, 2, 2) and taps["path1"].shape == (2, 256, 32, 32)
     y1 = M.midas_forward(x[1:], sd)
     assert torch.allclose(y[1:], y1, rtol=1e-4, atol=1e-4 * float(y.abs().max()))
+
+
+@pytest.mark.parametrize("img,B", [(128, 2), (384, 1)])
+def test_oracle_pinned_to_the_published_dpt_hybrid_implementation(img, B):
+    """oracle/midas_ref.py against Hugging Face `transformers` DPTForDepthEstimation(is_hybrid=True) -- an independent, published
+    implementation of DPT-Hybrid (the class the converted MiDaS `dpt_hybrid` checkpoint runs on) -- on the same key-hashed
+    weights and seeded input: 12 stage taps and the depth map, fp32 vs fp32, rel-L2 <= 1e-4 at the sampled positions, tap means /
+    norms to 1e-4, the whole depth map at 128^2.  Fixture: tests/golden/midas_hf.npz (tests/golden/gen_golden_midas.py, build
+    container only).  This replaces "both sides share my reading of the paper" by a check against a second implementation;
+    the reference's own MiDaS submodule is still absent, so the row stays flagged in DESIGN.md."""
+    import os
+    import sys
+
+    import numpy as np
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, golden)
+    from gen_golden_midas import TAPS, sample_index
+    from live2diff_amd.midas_hip import random_midas_state_dict
+    from oracle import midas_ref as M
+    g = dict(np.load(os.path.join(golden, "midas_hf.npz")))
+    sd = random_midas_state_dict(dtype=torch.float32, img=img)
+    x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(900 + img))
+    taps = {}
+    depth = M.midas_forward(x, sd, taps)
+    taps["depth"] = depth
+    assert set(TAPS) <= set(taps)
+    for name in TAPS + ("depth",):
+        flat = taps[name].reshape(-1).double()
+        want = torch.from_numpy(g[f"{img}.{name}.samples"]).double()
+        mean, norm, numel = g[f"{img}.{name}.stats"]
+        assert flat.numel() == int(numel), (name, flat.numel(), numel)
+        got = flat[sample_index(flat.numel(), f"{img}.{name}")]
+        err = ((got - want).norm() / want.norm().clamp_min(1e-12)).item()
+        assert err <= 1e-4, f"{img} {name}: rel-L2 {err:.2e} vs the HF implementation"
+        assert abs(flat.norm().item() / norm - 1) <= 1e-4 and abs(flat.mean().item() - mean) <= 1e-4 * max(1.0, abs(mean)), name
+    if img == 128:
+        full = torch.from_numpy(g["128.depth.full"]).double()
+        assert ((depth.double() - full).norm() / full.norm()).item() <= 1e-4
