@@ -232,6 +232,61 @@ def baseline_metric() -> str:
         return "frames/sec @512\u00d7512, 2 denoise steps; per-step latency; 1/2/4/8 GPU"
 
 
+def pipeline_whole_frame(unet, cfg, args, dev, N, sink, kv):
+    """The reference's published FPS definition (README.md:43-50 / test.py:201-205), measured through THIS repo's pipeline
+    class: `StreamAnimateDiffusionDepth.__call__` per frame = preprocess + encode_image (TAESD encode, noise draw + add_noise)
+    + encode_depth (384x384 resize, DPT-Hybrid detector, min-max / resize, TAESD encode) + predict_x0_batch (UNet, LCM step,
+    shift register, re-noising, ring buffer: the device step) + decode_image().clip, with the reference's own timing tail
+    (events around the call, a global synchronize, `inference_time_ema` = 0.9 ema + 0.1 t; pipeline :625-660).  Backends:
+    HipStreamingUNet + HipTinyVAE + HipMidas + HipDepthGlue on random-init weights of the published architectures; `prepare()`
+    runs the real warm-up (N warm-up UNet passes over 8 frames) first.  The text encoder runs once per prompt: excluded."""
+    from types import SimpleNamespace
+
+    from live2diff_amd.midas_hip import HipMidas, random_midas_state_dict
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth
+    from live2diff_amd.vae_hip import HipTinyVAE, random_taesd_state_dict
+    vae = HipTinyVAE(random_taesd_state_dict(device=dev), device=dev)
+    detector = HipMidas(random_midas_state_dict(device=dev), device=dev)
+    pipe = SimpleNamespace(device=dev, vae_scale_factor=8, unet=unet, vae=vae, depth_model=detector, scheduler=None)
+    t_index = {1: [40], 2: [30, 40], 4: [25, 31, 37, 43]}.get(N, list(range(50 - 6 * N, 50, 6))[:N])
+    s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=t_index, width=args.width, height=args.height,
+                                    do_add_noise=True, warmup_frames=sink, window_size=cfg.window_size)
+    s.image_processor.assume_unit_range = True           # frames arrive in [0, 1] (what the reference's callers feed)
+    gcpu = torch.Generator().manual_seed(4321)
+    warm = [torch.rand(3, args.height, args.width, generator=gcpu) for _ in range(sink)]
+    emb = torch.randn(1, 77, cfg.cross_attention_dim, generator=gcpu)
+    s.prepare_cache(args.height, args.width, N)
+    s.prepare(warm, prompt_embeds=emb, seed=3)
+    s.enable_device_step()
+    frames = [torch.rand(1, 3, args.height, args.width, generator=gcpu).to(dev) for _ in range(4)]
+    nwarm, nw = 8, max(10, min(40, args.steps))
+    for i in range(nwarm):
+        out = s(frames[i % 4])
+    s.inference_time_list.clear()
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    for i in range(nw):
+        out = s(frames[i % 4])
+    torch.cuda.synchronize()
+    tw = (time.perf_counter() - tw) / nw
+    lst = sorted(s.inference_time_list[-nw:])
+    # the pipeline owned its own KV caches and conditioning: point the UNet's plan back at the benchmark's before they go away
+    st = unet._plans["stream"]
+    unet._bind_caches(st, kv)
+    unet.invalidate_text_cache()
+    return {"frames_per_s": round(1.0 / tw, 2), "ms_per_frame": round(1e3 * tw, 3),
+            "inference_time_ema_ms": round(1e3 * s.inference_time_ema, 3), "inference_time_p50_ms": round(1e3 * lst[len(lst) // 2], 3),
+            "depth_time_ema_ms": round(1e3 * s.depth_time_ema, 3), "finite": bool(torch.isfinite(out).all()),
+            "path": "StreamAnimateDiffusionDepth.__call__ (this repo's mirror of pipeline_stream_animation_depth.py:625-660) with "
+                    "HipStreamingUNet + HipTinyVAE + HipMidas + device step, after prepare(); wall clock per call incl. the "
+                    "reference's per-frame torch.cuda.synchronize()",
+            "excludes": "text encoder (runs once per prompt)",
+            "reference_published_context": "README.md:43-50: 16.43 FPS (TensorRT) / 6.91 FPS (none) on an RTX 4090, 512x512, 2 steps "
+                                           "-- other hardware, context only",
+            "vae_launches": {str(k): v_["n_ops"] for k, v_ in vae.plan_summary().items()},
+            "depth_detector_launches": {str(k): v_["n_ops"] for k, v_ in detector.plan_summary().items()}}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` from a bare shell: re-exec this command line under torch.distributed.run, one rank per
     GPU of this node (rendezvous on 127.0.0.1, free port).  Rank 0 of the child job prints the JSON line."""
@@ -390,35 +445,7 @@ def main():
     whole = None
     if rank == 0 and args.whole_frame and dstep is None and (args.height % 8 == 0 and args.width % 8 == 0):
         try:
-            from live2diff_amd.midas_hip import HipMidas, random_midas_state_dict
-            from live2diff_amd.vae_hip import HipDepthGlue, HipTinyVAE, random_taesd_state_dict
-            vae = HipTinyVAE(random_taesd_state_dict(device=dev), device=dev)
-            glue = HipDepthGlue(dev)
-            detector = HipMidas(random_midas_state_dict(device=dev), device=dev)
-            img = torch.rand(1, 3, args.height, args.width, generator=g, device=dev, dtype=torch.float16) * 2 - 1
-
-            def frame():
-                lat = vae.encode(img).latents
-                dmap = detector(glue.resize(img, 384, 384))
-                dlat = vae.encode(glue.normalize_resize(dmap, args.height, args.width)).latents
-                x[:1].copy_(lat.view(1, 4, 1, h, w))
-                d[:1].copy_(dlat.view(1, 4, 1, h, w))
-                o = step()["sample"]
-                return vae.decode(o[-1:, :, 0], return_dict=False)[0]
-            for _ in range(5):
-                frame()
-            torch.cuda.synchronize()
-            tw = time.perf_counter()
-            nw = max(10, min(40, args.steps))
-            for _ in range(nw):
-                im = frame()
-            torch.cuda.synchronize()
-            tw = (time.perf_counter() - tw) / nw
-            whole = {"frames_per_s": round(1.0 / tw, 2), "ms_per_frame": round(1e3 * tw, 3), "finite": bool(torch.isfinite(im).all()),
-                     "includes": "TAESD encode (frame) + 384x384 resize + DPT-Hybrid depth detector + min-max / resize + TAESD encode "
-                                 "(depth map) + UNet step + TAESD decode", "excludes": "text encoder (runs once per prompt)",
-                     "vae_launches": {str(k): v_["n_ops"] for k, v_ in vae.plan_summary().items()},
-                     "depth_detector_launches": {str(k): v_["n_ops"] for k, v_ in detector.plan_summary().items()}}
+            whole = pipeline_whole_frame(unet, cfg, args, dev, N, sink, kv)
         except Exception as e:  # noqa: BLE001  -- informational figure: never fails the benchmark
             whole = {"error": repr(e)}
 

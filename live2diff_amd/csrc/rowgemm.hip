@@ -52,7 +52,18 @@ struct RowGemmArgs {
     int nm, ny, ytr, tr_n0, order;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
     float eps, inv_cpg;
+#ifdef L2D_PROBES
+    unsigned long long *probe;     // analysis builds: 8 s_memtime stamps per block (thread 0), tools/rowgemm_probe.py
+#endif
 };
+
+#ifdef L2D_PROBES
+static unsigned long long *g_rowgemm_probe = nullptr;
+extern "C" void l2d_rowgemm_set_probe(void *p) { g_rowgemm_probe = (unsigned long long *)p; }
+#define RG_STAMP(i) do { if (a.probe && threadIdx.x == 0) a.probe[(unsigned long long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RG_STAMP(i) do { } while (0)
+#endif
 
 template <int RD, int SK>
 constexpr int rg_ring() { return SK > 0 ? (RD < SK ? RD : SK) : 4; }
@@ -133,6 +144,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
     }
 
     // ------------------------------------------------------------------------------------------------- epilogue
+    RG_STAMP(4);                                             // k loop done (issue side)
     const int BNp = NW * NT * 32;                            // packed weight rows of this block
     const int BNo = a.epi == 1 ? BNp >> 1 : BNp;             // output columns
     const int nb_p = y * BNp, nb_o = y * BNo;
@@ -223,6 +235,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
         }
     }
     __syncthreads();
+    RG_STAMP(5);                                             // tile staged in LDS, residual requested
     const bool gn = a.gn1 != nullptr;
     float gs[4], gq[4];
 #pragma unroll
@@ -244,6 +257,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
             }
         }
     }
+    RG_STAMP(6);                                             // row stores issued
     if (gn) {
         // statistics of what was just stored (the fp16 values the consumer GroupNorm will read), per channel pair,
         // reduced to the consumer's groups inside the block, two integer atomics per (consumer, overlapped group)
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthr = blockDim.x, NW = nthr >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RG_STAMP(0);                                              // block entry
 
     // XCD-aware block order (blocks are dispatched round-robin over the 8 XCDs): every XCD runs a contiguous range of work
     // items, token-tile major (activations dominate: level 0) or weight-band major (order 1: the weight band of an XCD stays
@@ -301,6 +316,7 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) wr[s][i] = l2d_ld8(wp + i * tstride + s * 512);
     __builtin_amdgcn_sched_barrier(0);
+    RG_STAMP(1);                                              // weight ring requested
 
     // ---- GroupNorm prologue: (rstd, -mean rstd) per channel of this block's sample (the block lies inside one sample; gamma
     // and beta live in the packed weight / bias).  One dependent read of the 512-byte accumulator block, no parameter loads.
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
         __syncthreads();
     }
 
+    RG_STAMP(2);                                              // GroupNorm tables ready (prologue 2)
     // ---- activation tile -> LDS.  Thread (row r = tid / LPR, j = tid % LPR) moves the 16-byte slots q = j + LPR i of its
     // row (LPR = 8 lanes per row, 16 when the block has the threads and K % 128 == 0: half as many dependent load groups for
     // K = 1280): the lanes of a row read 128 / 256 contiguous bytes per step; slot q of token r lands at
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
         }
     }
     __syncthreads();
+    RG_STAMP(3);                                              // activation tile normalised and visible
     rowgemm_body<NT, MT, RD, SK>(a, smem, wr, wp, tstride, S, m0, y, NW, wave, lane, tid, nthr);
 }
 
@@ -438,6 +456,9 @@ int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s) {
     a.ldt = op->i[16]; a.order = op->i[17] ? 1 : 0;
     a.sT = op->l[0];
     a.eps = op->f[0];
+#ifdef L2D_PROBES
+    a.probe = g_rowgemm_probe;
+#endif
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     const int BM = 32 * MT;

@@ -1,4 +1,4 @@
-// Streaming temporal attention, LDS-DMA ring kernel (SD widths C = 320 / 640 / 1280, window L = 12 / 16).
+// Streaming temporal attention, LDS-DMA ring kernel (SD widths C = 320 / 640 / 1280, window L = 12 / 16 / 24 / 40).
 // Same math and rounding points as tattn_stream_kernel (tattn.hip; reference stream_motion_module.py:99-213).
 //
 // Why: the register-resident kernel issues all 2L loads of a pixel, waits, then computes; per cfg-2 frame that is
@@ -114,11 +114,12 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
     const int u = __builtin_amdgcn_readfirstlane((int)a.update_idx[n]);
     const long long *pei = a.pe_idx + (long long)n * L;
     const h16 *bi = a.bias + (long long)n * L;
-    unsigned live = 0;                              // bit l: slot l is fetched from the cache
+    unsigned long long live = 0;                    // bit l: slot l is fetched from the cache (L up to 40: 64 bits)
 #pragma unroll
     for (int l = 0; l < L; ++l)
-        if ((float)bi[l] > -1e30f && l != u) live |= 1u << l;
-    live = __builtin_amdgcn_readfirstlane(live);
+        if ((float)bi[l] > -1e30f && l != u) live |= 1ull << l;
+    live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(live >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(live & 0xffffffffull));
     if (tid < L) blds[tid] = (float)bi[tid];        // visible after the first stage barrier
     // gathered PE rows of this chunk -> LDS by DMA (older than every ring load: landed before the first stage is
     // consumed, visible to the block after that stage's barrier).  L * 40 items of 16 B per table.
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
             const int l = l0 + j;                                // uniform
-            const unsigned long long lv = 0ull - (unsigned long long)((live >> l) & 1u);        // all ones: live slot
+            const unsigned long long lv = 0ull - ((live >> l) & 1ull);                          // all ones: live slot
             const unsigned long long nw = (0ull - (unsigned long long)(l == u ? 1u : 0u)) & ~lv; // all ones: the new row
             const unsigned long long sb = ((unsigned long long)(cb + l * C) & lv) | ((unsigned long long)qb & nw) |
                                           ((unsigned long long)zero & ~(lv | nw));
@@ -293,13 +294,21 @@ static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_
     if (g == -1) g = 0;
     (void)groups16;
     if (g == 2 && a.T % 16 != 0) g = 0;
-    if (g == 1) launch_ring_g<L, HG, 2, 3, 8>(a, zero, 2 * cus, s);
-    else if (g == 2) launch_ring_g<L, HG, 2, 4, 16>(a, zero, cus, s);
-    else launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s);
+    if constexpr (L <= 16) {
+        if (g == 1) launch_ring_g<L, HG, 2, 3, 8>(a, zero, 2 * cus, s);
+        else if (g == 2) launch_ring_g<L, HG, 2, 4, 16>(a, zero, cus, s);
+        else launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s);
+    } else if constexpr (L == 24) {
+        // longer windows: the score rows ([320][L + 4] f32) and the gathered PE rows (2 x L x 640 B) grow with L, the ring
+        // gets what is left of the 160 KB: 4 stages x 4 rows (80 KB) at L = 24, 5 stages x 2 rows (50 KB) at L = 40
+        launch_ring_g<L, HG, 4, 4, 8>(a, zero, cus, s);
+    } else {
+        launch_ring_g<L, HG, 2, 5, 8>(a, zero, cus, s);
+    }
 }
 
 bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
-    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12) && (a.T % 8 == 0) && a.H == 8;
+    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12 || a.L == 24 || a.L == 40) && (a.T % 8 == 0) && a.H == 8;
 }
 
 int l2d_launch_tattn_ring(const TAttnArgs &a, const void *zero_page, hipStream_t s) {
@@ -315,10 +324,18 @@ int l2d_launch_tattn_ring(const TAttnArgs &a, const void *zero_page, hipStream_t
         if (a.C == 320) launch_ring<16, 5>(a, zero, cus, s);
         else if (a.C == 640) launch_ring<16, 10>(a, zero, cus, s);
         else launch_ring<16, 20>(a, zero, cus, s);
-    } else {
+    } else if (a.L == 12) {
         if (a.C == 320) launch_ring<12, 5>(a, zero, cus, s);
         else if (a.C == 640) launch_ring<12, 10>(a, zero, cus, s);
         else launch_ring<12, 20>(a, zero, cus, s);
+    } else if (a.L == 24) {
+        if (a.C == 320) launch_ring<24, 5>(a, zero, cus, s);
+        else if (a.C == 640) launch_ring<24, 10>(a, zero, cus, s);
+        else launch_ring<24, 20>(a, zero, cus, s);
+    } else {
+        if (a.C == 320) launch_ring<40, 5>(a, zero, cus, s);
+        else if (a.C == 640) launch_ring<40, 10>(a, zero, cus, s);
+        else launch_ring<40, 20>(a, zero, cus, s);
     }
     return L2D_OK;
 }
