@@ -35,6 +35,8 @@
 // Roofline note: with BM = 32 every weight fragment (1 KB) feeds ONE 32x32x16 MFMA (32 cycles on its SIMD), i.e.
 // 128 B/clk/CU of L1 traffic at full matrix rate against a 64 B/clk/CU path: this structure tops out at ~0.5 of the MFMA
 // peak (BM = 64: 1.0).  It is built for the latency-bound launches (1-15 GFLOP each), not for the 3x3 convolutions.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,6 +67,20 @@ extern "C" void l2d_rowgemm_set_probe(void *p) { g_rowgemm_probe = (unsigned lon
 #define RG_STAMP(i) do { } while (0)
 #endif
 
+// sum over the 8 (or 16) adjacent lanes that hold one activation row, on DPP (no LDS crossbar round trips): xor 1 and xor 2
+// inside the quad, then the mirror partner inside the half row (the other quad, whose lanes all hold that quad's sum), then
+// the mirror partner inside the row of 16
+__device__ __forceinline__ float rg_row_sum(float v, bool wide) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    if (wide) v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
 template <int RD, int SK>
 constexpr int rg_ring() { return SK > 0 ? (RD < SK ? RD : SK) : 4; }
 
@@ -73,8 +89,8 @@ constexpr int rg_ring() { return SK > 0 ? (RD < SK ? RD : SK) : 4; }
 // exposed L2 round trip per 4 k steps -- only the unit-test widths and the odd layer take this path).
 template <int NT, int MT, int RD, int SK>
 __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h16x8 (&wr)[rg_ring<RD, SK>()][NT], const h16 *wp,
-                                             long long tstride, int S, int m0, int y, int NW, int wave, int lane, int tid,
-                                             int nthr) {
+                                             int wlane, long long tstride, int S, int m0, int y, int NW, int wave, int lane,
+                                             int tid, int nthr) {
     constexpr int BM = 32 * MT;
     const int l32 = lane & 31, lh = lane >> 5;
     f32x16 acc[NT][MT];
@@ -93,9 +109,35 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xoff[u][mt] = (((2 * u + lh) * BM) + 32 * mt + (l32 ^ (4 * u + 2 * lh))) * 8;
 
+    // ---- epilogue geometry: whole output rows, 16 bytes per lane: thread -> (row rr + it * RPP, 8-channel chunk cc); cc is the
+    // same in every pass, which is what lets a thread keep per-channel GroupNorm sums in registers.  The residual rows are
+    // requested HERE, in front of the k loop (they are older than every weight refill in the in-order VMEM queue and land under
+    // the MFMAs), not after it where they would be one more exposed round trip.
+    const int BNp = NW * NT * 32;                            // packed weight rows of this block
+    const int BNo = a.epi == 1 ? BNp >> 1 : BNp;             // output columns
+    const int nb_p = y * BNp, nb_o = y * BNo;
+    constexpr int RPPC = 16 / NT;                            // rows per pass without GEGLU (64 NW threads / (4 NW NT) chunks)
+    constexpr int EIT = (BM + RPPC - 1) / RPPC;
+    const int CPR = BNo >> 3;
+    const int RPP = nthr / CPR;
+    const int rr = tid / CPR, cc = tid - rr * CPR;
+    const bool on = rr < RPP;
+    h16x8 resv[EIT];
+    if (a.res && y < a.ytr) {
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            int row = rr + it * RPP;
+            row = (on && row < BM && m0 + row < a.M) ? row : 0;    // (clamped: an unconditional load, selected below)
+            resv[it] = l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + (on ? cc : 0) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     if constexpr (SK > 0) {
         constexpr int RDC = rg_ring<RD, SK>();               // (the first RDC k steps were requested at kernel entry)
         h16x8 xf[2][MT];
+        long long wcur = RDC * 512;                          // element offset of the next fragment of tile 0 to request
+        asm volatile("" : "+s"(wcur));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[0][mt] = l2d_ld8(smem + xoff[0][mt]);
 #pragma unroll
@@ -111,7 +153,11 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
                     acc[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % RDC][i], xf[s & 1][mt], acc[i][mt], 0, 0, 0);
             if (s + RDC < SK) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) wr[s % RDC][i] = l2d_ld8(wp + i * tstride + (s + RDC) * 512);
+                for (int i = 0; i < NT; ++i) wr[s % RDC][i] = l2d_ld8(wp + (wcur + i * tstride) + wlane);
+                // one running (wave-uniform) offset, opaque to the optimiser: otherwise the address of every refill of the
+                // straight-line loop is computed at the top and stays live -- 64-bit VGPR pairs by the dozen, spills at K = 1280
+                wcur += 512;
+                asm volatile("" : "+s"(wcur));
             }
             __builtin_amdgcn_sched_barrier(0);               // the refills stay HERE: RDC - 1 k steps ahead of their use
         }
@@ -122,7 +168,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) nxt[u][i] = l2d_ld8(wp + i * tstride + (long long)(s0 + 4 + u) * 512);
+                    for (int i = 0; i < NT; ++i) nxt[u][i] = l2d_ld8(wp + (i * tstride + (long long)(s0 + 4 + u) * 512) + wlane);
             }
             const h16 *xb = smem + (s0 >> 2) * (64 * BM);
 #pragma unroll
@@ -145,9 +191,6 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
 
     // ------------------------------------------------------------------------------------------------- epilogue
     RG_STAMP(4);                                             // k loop done (issue side)
-    const int BNp = NW * NT * 32;                            // packed weight rows of this block
-    const int BNo = a.epi == 1 ? BNp >> 1 : BNp;             // output columns
-    const int nb_p = y * BNp, nb_o = y * BNo;
     h16 *os = smem;
     __syncthreads();                                         // every wave is done reading the activation tile
     if (y >= a.ytr) {
@@ -217,23 +260,7 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
             }
         }
     }
-    // whole rows, 16 bytes per lane: thread -> (row rr + it * RPP, 8-channel chunk cc); cc is the same in every pass,
-    // which is what lets a thread keep per-channel GroupNorm sums in registers
-    constexpr int RPPC = 16 / NT;                            // rows per pass without GEGLU (64 NW threads / (4 NW NT) chunks)
-    constexpr int EIT = (BM + RPPC - 1) / RPPC;
-    const int CPR = BNo >> 3;
-    const int RPP = nthr / CPR;
-    const int rr = tid / CPR, cc = tid - rr * CPR;
-    const bool on = rr < RPP;
-    h16x8 resv[EIT];
-    if (a.res) {
-#pragma unroll
-        for (int it = 0; it < EIT; ++it) {
-            int row = rr + it * RPP;
-            row = (row < BM && m0 + row < a.M) ? row : 0;    // (clamped: an unconditional load, selected below)
-            resv[it] = l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + cc * 8);
-        }
-    }
+    // whole rows, 16 bytes per lane (the residual rows were requested before the k loop)
     __syncthreads();
     RG_STAMP(5);                                             // tile staged in LDS, residual requested
     const bool gn = a.gn1 != nullptr;
@@ -305,17 +332,27 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
     const int KK = SK > 0 ? SK * 16 : a.K;
     const int t0 = (y * NW + wave) * NT;                      // this wave's first 32-row weight tile
 
-    // ---- weight stream: the first ring of fragments leaves NOW, before anything else needs the memory pipe: it flies
-    // under the activation load and the normalisation
-    const h16 *wp = a.w + ((long long)t0 * S * 64 + lane) * 8;
+    // ---- weight stream: fragment-packed weights of this wave's tiles.  The first ring of fragments is requested right behind
+    // the FIRST group of activation loads (below), not in front of them: VMEM returns in order and a CU ingests only ~20-30
+    // bytes per clock when every block of the launch bursts at once, so 16 KB of weights per wave queued ahead of the
+    // activation rows delayed the normalisation -- the head of the block's critical path -- by the whole ring's transfer time.
+    // (wave-uniform base in SGPRs + one constant per-lane offset: the straight-line k loop then needs no per-load address VGPRs)
+    const h16 *wp = a.w + (long long)t0 * S * 512;
+    const int wlane = lane * 8;
     const long long tstride = (long long)S * 512;             // halfs between consecutive 32-row weight tiles
     constexpr int RING = rg_ring<RD, SK>();
     h16x8 wr[RING][NT];
+    auto request_ring = [&]() {
+        long long ro = 0;                                     // running wave-uniform element offset, opaque to the optimiser (the
+#pragma unroll                                                // OFFSET, not the pointer: a pointer that went through an asm
+        for (int s = 0; s < RING; ++s) {                      // statement loses its address space and its loads become flat_load,
+            asm volatile("" : "+s"(ro));                      // which count on lgkmcnt too and cannot be waited for selectively)
 #pragma unroll
-    for (int s = 0; s < RING; ++s)
-#pragma unroll
-        for (int i = 0; i < NT; ++i) wr[s][i] = l2d_ld8(wp + i * tstride + s * 512);
-    __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < NT; ++i) wr[s][i] = l2d_ld8(wp + (ro + i * tstride) + wlane);
+            ro += 512;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     RG_STAMP(1);                                              // weight ring requested
 
     // ---- GroupNorm prologue: (rstd, -mean rstd) per channel of this block's sample (the block lies inside one sample; gamma
@@ -347,76 +384,135 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
     // ---- activation tile -> LDS.  Thread (row r = tid / LPR, j = tid % LPR) moves the 16-byte slots q = j + LPR i of its
     // row (LPR = 8 lanes per row, 16 when the block has the threads and K % 128 == 0: half as many dependent load groups for
     // K = 1280): the lanes of a row read 128 / 256 contiguous bytes per step; slot q of token r lands at
-    // ((q * BM) + (r ^ 2 (q & 7))) * 16 B.  Loads go out in groups of 5 slots per thread (K = 320: the whole row at once),
+    // ((q * BM) + (r ^ 2 (q & 7))) * 16 B.  Loads go out in groups of 10 slots per thread (K <= 640: the whole row at once),
     // unconditionally (rows beyond M are clamped and zeroed afterwards: a select around a load would become a branch per load).
+    // Order of requests: every (row, group) pair of this thread but the last is loaded and consumed in a loop; the LAST pair is
+    // requested, then -- in straight-line code, so that the compiler can count the loads behind it -- the weight ring, then
+    // the last pair is consumed: the activation rows never queue behind the weights, and the ring is still in flight
+    // (not drained by a conservative vmcnt(0)) when the k loop starts.
     {
+        constexpr int XG = 10;                                // slots per thread and load group: K <= 640 (1280 with 16 lanes per row) is ONE group
         const bool wide = nthr >= 16 * BM && (KK & 127) == 0;
         const int lsh = wide ? 4 : 3, LPR = 1 << lsh;
         const int KS = KK >> (3 + lsh);
+        const int nch = (KS + XG - 1) / XG;                   // load groups per row
         const int j = tid & (LPR - 1);
         const int dstep = 8 * LPR * BM;                       // halfs between slots q and q + LPR
-        for (int r = tid >> lsh; r < BM; r += (nthr >> lsh)) {
+        const int r0 = tid >> lsh, rstep = nthr >> lsh;
+        const bool has_row = r0 < BM;
+        const int r_last = has_row ? r0 + ((BM - 1 - r0) / rstep) * rstep : 0;
+        const bool ln_reg = a.pro == 1 && nch == 1;           // the thread's whole row slice is one load group: LayerNorm in registers
+
+        auto load_group = [&](h16x8 (&v)[XG], int r, int i0) {
             const int m = m0 + r;
-            const bool rv = m < a.M;
-            const h16 *src = a.x + (long long)(rv ? m : 0) * a.ldx + j * 8;
+            const h16 *src = a.x + (long long)(m < a.M ? m : 0) * a.ldx + j * 8;
+#pragma unroll
+            for (int u = 0; u < XG; ++u) v[u] = l2d_ld8(src + (i0 + u < KS ? i0 + u : KS - 1) * (8 * LPR));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // consumes one group; `s` carries the row sum of the LDS-based LayerNorm across the groups of a row
+        auto consume_group = [&](h16x8 (&v)[XG], int r, int i0, float &s) {
+            const bool rv = m0 + r < a.M;
             h16 *dst = smem + (j * BM + (r ^ (2 * (j & 7)))) * 8;
-            float s = 0.f;
-            for (int i0 = 0; i0 < KS; i0 += 5) {
-                h16x8 v[5];
+            if (ln_reg) {
+                // exact two-pass statistics on the registers, one LDS store per slot
+                float t = 0.f;
 #pragma unroll
-                for (int u = 0; u < 5; ++u) v[u] = l2d_ld8(src + (i0 + u < KS ? i0 + u : KS - 1) * (8 * LPR));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    if (i0 + u >= KS) break;
+                for (int u = 0; u < XG; ++u) {
+                    if (u >= KS) break;
                     if (!rv) v[u] = l2d_zero8();
-                    if (a.pro == 2) {
-                        const int c0 = (j + LPR * (i0 + u)) * 8;
-                        const f32x4 sa = *reinterpret_cast<const f32x4 *>(tab + c0), sb = *reinterpret_cast<const f32x4 *>(tab + c0 + 4);
-                        const f32x4 ha = *reinterpret_cast<const f32x4 *>(tab + KK + c0), hb = *reinterpret_cast<const f32x4 *>(tab + KK + c0 + 4);
-                        h16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            o[e] = (h16)((float)v[u][e] * sa[e] + ha[e]);
-                            o[4 + e] = (h16)((float)v[u][4 + e] * sb[e] + hb[e]);
-                        }
-                        v[u] = rv ? o : l2d_zero8();
-                    } else if (a.pro == 1) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) s += (float)v[u][e];
-                    }
-                    l2d_st8(dst + (i0 + u) * dstep, v[u]);
+                    for (int e = 0; e < 8; ++e) t += (float)v[u][e];
                 }
-            }
-            if (a.pro == 1) {
-                // LayerNorm statistics, exact two-pass: the raw row was parked in LDS above and is re-read by its own thread
-                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-                if (wide) s += __shfl_xor(s, 8, 64);
-                const float mean = s / (float)KK;
+                const float mean = rg_row_sum(t, wide) / (float)KK;
                 float q = 0.f;
-#pragma unroll 5
-                for (int i = 0; i < KS; ++i) {
-                    const h16x8 v = l2d_ld8(dst + i * dstep);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q += d * d; }
+                for (int u = 0; u < XG; ++u) {
+                    if (u >= KS) break;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = (float)v[u][e] - mean; q += d * d; }
                 }
-                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-                if (wide) q += __shfl_xor(q, 8, 64);
-                const float rstd = rsqrtf(q / (float)KK + a.eps);
-#pragma unroll 5
-                for (int i = 0; i < KS; ++i) {
-                    const h16x8 v = l2d_ld8(dst + i * dstep);
+                const float rstd = rsqrtf(rg_row_sum(q, wide) / (float)KK + a.eps);
+#pragma unroll
+                for (int u = 0; u < XG; ++u) {
+                    if (u >= KS) break;
                     h16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[e] - mean) * rstd);
-                    l2d_st8(dst + i * dstep, o);
+                    for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[u][e] - mean) * rstd);
+                    l2d_st8(dst + u * dstep, o);
+                }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < XG; ++u) {
+                if (i0 + u >= KS) break;
+                if (!rv) v[u] = l2d_zero8();
+                if (a.pro == 2) {
+                    const int c0 = (j + LPR * (i0 + u)) * 8;
+                    const f32x4 sa = *reinterpret_cast<const f32x4 *>(tab + c0), sb = *reinterpret_cast<const f32x4 *>(tab + c0 + 4);
+                    const f32x4 ha = *reinterpret_cast<const f32x4 *>(tab + KK + c0), hb = *reinterpret_cast<const f32x4 *>(tab + KK + c0 + 4);
+                    h16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (h16)((float)v[u][e] * sa[e] + ha[e]);
+                        o[4 + e] = (h16)((float)v[u][4 + e] * sb[e] + hb[e]);
+                    }
+                    v[u] = rv ? o : l2d_zero8();
+                } else if (a.pro == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += (float)v[u][e];
+                }
+                l2d_st8(dst + (i0 + u) * dstep, v[u]);
+            }
+        };
+        // LayerNorm of a row wider than one load group: exact two-pass on the raw row parked in LDS (re-read by its own thread)
+        auto finish_row_lds = [&](int r, float s) {
+            h16 *dst = smem + (j * BM + (r ^ (2 * (j & 7)))) * 8;
+            const float mean = rg_row_sum(s, wide) / (float)KK;
+            float q = 0.f;
+#pragma unroll 5
+            for (int i = 0; i < KS; ++i) {
+                const h16x8 v = l2d_ld8(dst + i * dstep);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q += d * d; }
+            }
+            const float rstd = rsqrtf(rg_row_sum(q, wide) / (float)KK + a.eps);
+#pragma unroll 5
+            for (int i = 0; i < KS; ++i) {
+                const h16x8 v = l2d_ld8(dst + i * dstep);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[e] - mean) * rstd);
+                l2d_st8(dst + i * dstep, o);
+            }
+        };
+
+        float srow = 0.f;
+        if (has_row) {
+            for (int r = r0; r < BM; r += rstep) {
+                const int ng = (r == r_last) ? nch - 1 : nch;  // the last group of the last row is peeled below
+                for (int c = 0; c < ng; ++c) {
+                    h16x8 v[XG];
+                    load_group(v, r, c * XG);
+                    consume_group(v, r, c * XG, srow);
+                }
+                if (r != r_last) {
+                    if (a.pro == 1 && !ln_reg) finish_row_lds(r, srow);
+                    srow = 0.f;
                 }
             }
+        }
+        h16x8 vl[XG];
+        if (has_row) load_group(vl, r_last, (nch - 1) * XG);
+        request_ring();
+        if (has_row) {
+            consume_group(vl, r_last, (nch - 1) * XG, srow);
+            if (a.pro == 1 && !ln_reg) finish_row_lds(r_last, srow);
         }
     }
     __syncthreads();
     RG_STAMP(3);                                              // activation tile normalised and visible
-    rowgemm_body<NT, MT, RD, SK>(a, smem, wr, wp, tstride, S, m0, y, NW, wave, lane, tid, nthr);
+    rowgemm_body<NT, MT, RD, SK>(a, smem, wr, wp, wlane, tstride, S, m0, y, NW, wave, lane, tid, nthr);
 }
 
 template <int NT, int MT, int RD, int SK, int MAXT>
@@ -505,10 +601,11 @@ int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     L2D_DRY_RETURN();
-    // ring depth (fragments in flight per wave and tile): 16 KB per wave for NT = 1, 8 KB per tile otherwise
+    // ring depth (fragments in flight per wave and tile): up to 24 KB per wave for NT = 1 (the K = 1280 levels are bound by the
+    // latency of their weight stream: 80 KB per wave), 8 KB per tile otherwise
     if (MT == 1) {
         switch (NT) {
-            case 1: launch_k<1, 1, 16, 512>(a, nthr, lds, s); break;
+            case 1: launch_k<1, 1, 24, 512>(a, nthr, lds, s); break;
             case 2: launch_k<2, 1, 8, 512>(a, nthr, lds, s); break;
             case 3: launch_k<3, 1, 5, 320>(a, nthr, lds, s); break;
             default: launch_k<4, 1, 4, 320>(a, nthr, lds, s); break;

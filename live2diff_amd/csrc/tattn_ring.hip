@@ -308,7 +308,7 @@ static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_
 }
 
 bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
-    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12 || a.L == 24 || a.L == 40) && (a.T % 8 == 0) && a.H == 8;
+    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12 || a.L == 24) && (a.T % 8 == 0) && a.H == 8;
 }
 
 int l2d_launch_tattn_ring(const TAttnArgs &a, const void *zero_page, hipStream_t s) {

@@ -153,6 +153,7 @@ class HipStreamingUNet:
             W[name + ".b"] = ops.f32(g(name + ".bias"))
 
         use_rg = os.environ.get("L2D_ROWGEMM", "1") != "0"     # A/B knob: 0 = every linear layer on igemm + separate norm launches
+        RG_PLAIN_MAX_K = int(os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"))
 
         def rg_ok(wname):
             n, k = sd[wname].shape[0], sd[wname][0].numel()
@@ -162,7 +163,10 @@ class HipStreamingUNet:
             """Linear layer `name`; `norm` = the LayerNorm / GroupNorm whose output feeds it.  Token-row GEMM packing
             (rowgemm.hip: fragment order, the norm's affine folded into weight and bias) when the shape allows, else -- and
             with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
-            rg = rg_ok(name + ".weight")
+            # Row GEMM where it fuses a norm, and for the narrow levels (K <= 640).  A plain Linear at K = 1280 stays on the
+            # implicit-GEMM kernel: with 32-token row tiles every block ingests its whole weight band (80 KB per 32-row tile), and
+            # the probe (profiles/r3b_rowgemm_block_phases.txt) shows those launches bound by ~30 B/clk of ingest per CU.
+            rg = rg_ok(name + ".weight") and (norm is not None or sd[name + ".weight"][0].numel() <= RG_PLAIN_MAX_K)
             if rg:
                 W[name + ".rw"], rb = ops.pack_rowgemm(g(name + ".weight"), g(name + ".bias") if bias else None,
                                                        g(norm + ".weight") if norm else None, g(norm + ".bias") if norm else None)
