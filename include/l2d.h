@@ -160,6 +160,15 @@ enum {
  *   computes 32 MT tokens x 32 NW NT packed rows; (Nout / 32) % (NW NT) == 0 (ops.rowgemm_schedule)
  *   i15 trailing weight tiles stored transposed to p8 (% (NW NT)) i16 ldt i17 block order (1 = weight-band major per XCD)
  *   l0 elements between samples in p8 ; f0 eps of the prologue norm
+ *
+ * L2D_OP_PCONV     3x3 stride-1 pad-1 convolution with the haloed activation patch resident in LDS (pconv.hip; reference
+ *                InflatedConv3d resnet.py:57-65 as used by ResnetBlock3D :194,214): same result as L2D_OP_IGEMM with taps = 9,
+ *                stride 1, no upsample, epi 0; the activations are fetched once per 64-channel chunk instead of once per tap
+ *   p0 x1 [B,H,W,C1] half   p1 x2 [B,H,W,C2] half or 0 (channel concat)   p2 w packed [Nout][9 * CinP] half (ops.pack_conv3x3)
+ *   p3 bias float [Nout] or 0   p4 rowbias float [*][ldrb] or 0 (row = first token of the sample / i18)   p5 residual [M][ldr] half
+ *   or 0   p6 out [M][ldo] half   p7 16-byte zero page   p9 / p10, i24..i29 GroupNorm statistics of the output as L2D_OP_IGEMM
+ *   i1 C1 i2 C2 (both % 64) i3 ldx1 i4 ldx2 i5 CinP (= C1 + C2) i6 B i7 H i8 W i9 / i10 patch height / width (8x16, 8x8 or 4x8;
+ *   H % PH == 0, W % PW == 0) i11 block order (1 = weight-tile major) i14 Nout (% 64) i15 ldo i16 ldr i17 ldrb i18 rows_per_bias
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -185,6 +194,7 @@ enum {
     L2D_OP_RESAMPLE_NHWC = 21,
     L2D_OP_EW = 22,
     L2D_OP_ROWGEMM = 23,
+    L2D_OP_PCONV = 24,
 };
 
 typedef struct l2d_op {

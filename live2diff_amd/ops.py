@@ -173,13 +173,70 @@ def rowgemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int)
     return True
 
 
+def pconv_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """The same request to a patch-conv op (a patch never straddles samples)."""
+    assert op.kind == _lib.OP_PCONV
+    if T != op.i[7] * op.i[8] or G > 32 or (cpg | choff) & 1:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
+
+
 def gn_target(op, acc_ptr: int, **kw) -> bool:
-    """Ask the GEMM op that produced a tensor to accumulate that tensor's GroupNorm statistics (igemm or rowgemm)."""
+    """Ask the GEMM op that produced a tensor to accumulate that tensor's GroupNorm statistics (igemm, rowgemm or pconv)."""
     if op.kind == _lib.OP_IGEMM:
         return igemm_gn_target(op, acc_ptr, **kw)
     if op.kind == _lib.OP_ROWGEMM:
         return rowgemm_gn_target(op, acc_ptr, **kw)
+    if op.kind == _lib.OP_PCONV:
+        return pconv_gn_target(op, acc_ptr, **kw)
     return False
+
+
+def pconv_patch(B: int, H: int, W: int, Nout: int, C1: int, C2: int = 0):
+    """Patch (PH, PW) for the patch-resident 3x3 conv, or None when the implicit-GEMM kernel should take the launch: the largest
+    of 8x16 / 8x8 / 4x8 that tiles the image and yields >= 256 blocks of (patch, 64 output channels).  Not for the lowest
+    resolutions: with few tokens the launch is bound by its weight stream (9 C Nout x 2 bytes), which wants split-K."""
+    if os.environ.get("L2D_PCONV", "1") == "0" or Nout % 64 or C1 % 64 or C2 % 64 or C1 <= 0:
+        return None
+    force = os.environ.get("L2D_PCONV_PATCH")
+    for ph, pw in ((8, 16), (8, 8), (4, 8)):
+        if H % ph or W % pw:
+            continue
+        if force and force != f"{ph}x{pw}":
+            continue
+        blocks = B * (H // ph) * (W // pw) * (Nout // 64)
+        tokens = B * H * W
+        if blocks >= 256 and tokens >= int(os.environ.get("L2D_PCONV_MIN_TOKENS", "2048")):
+            return ph, pw
+    return None
+
+
+def pconv(x1, w, out, *, B, H, W, C1, ldx1, CinP, Nout, ldo, patch, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
+          rows_per_bias=0, res=None, ldr=0, order=None):
+    """3x3 stride-1 conv, activation patch resident in LDS (csrc/pconv.hip); `w` = pack_conv3x3 weights (as igemm)."""
+    op = L2dOp()
+    op.kind = _lib.OP_PCONV
+    zp = zero_page(x1.device)
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), (_ptr(x2) if x2 is not None else None), _ptr(_h(w))
+    op.p[3], op.p[4], op.p[5] = _ptr(bias), _ptr(rowbias), (_ptr(_h(res)) if res is not None else None)
+    op.p[6], op.p[7] = _ptr(_h(out)), _ptr(zp)
+    assert CinP == C1 + C2 and w.shape[1] == 9 * CinP and w.shape[0] == Nout
+    if order is None:
+        order = int(Nout * 9 * CinP > B * H * W * (C1 + C2))
+    vals = {1: C1, 2: C2, 3: ldx1, 4: ldx2, 5: CinP, 6: B, 7: H, 8: W, 9: patch[0], 10: patch[1], 11: order, 14: Nout, 15: ldo,
+            16: ldr, 17: ldrb, 18: rows_per_bias}
+    for j, v in vals.items():
+        op.i[j] = int(v)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp)
+
 
 
 def _rowgemm_lds(K, NW, NT, MT, epi, pro, ntr, gn):

@@ -487,6 +487,16 @@ class HipStreamingUNet:
             if rowbias is not None:
                 off = rowbias
                 kw = dict(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(Ho * Wo if mode == "stream" else B * Ho * Wo))
+            patch = ops.pconv_patch(B, Hin, Win, cout, x.C) if (stride == 1 and not ups and epi == 0 and cinp == x.C) else None
+            if patch is not None:
+                # resnet convs at the resolutions where a CU's ingest, not the matrix cores, bounds the implicit-GEMM kernel:
+                # activation patch resident in LDS, fetched once per 64-channel chunk instead of once per tap (pconv.hip)
+                op_ = add(ops.pconv(x.buf, wt, out.buf, B=B, H=Hin, W=Win, C1=x.C, ldx1=x.C, CinP=cinp, Nout=cout, ldo=cout, patch=patch,
+                                    bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0), **kw))
+                if rowbias is not None:
+                    op_.p[4] = st.temb_all.data_ptr() + 4 * rowbias
+                out.producer = op_
+                return out
             op_ = gemm(x.buf, wt, out.buf, M=B * Ho * Wo, Nout=cout, C1=x.C, ldx1=x.C, CinP=cinp, ldo=cout,
                             bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
                             taps=9, B=B, Hin=Hin, Win=Win, Hout=Ho, Wout=Wo, stride=stride, ups=ups, epi=epi, **kw)
