@@ -525,6 +525,15 @@ def main():
             result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc}
         my_frac = result["roofline"]["frac"]
+        # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
+        # rate is the figure comparable with the single igemm family of rounds 1-2
+        gem = [rows[k_] for k_ in ("igemm_kernel", "rowgemm_kernel", "pconv_kernel") if k_ in rows]
+        if gem:
+            gms, gfl = sum(g_["ms"] for g_ in gem), sum(g_["flops"] for g_ in gem)
+            result["roofline_gemm_kernels"] = {"kernels": [k_ for k_ in ("igemm_kernel", "rowgemm_kernel", "pconv_kernel") if k_ in rows],
+                                               "bound": "mfma", "launches": sum(g_["launches"] for g_ in gem), "ms_per_frame": round(gms, 4),
+                                               "achieved": round(gfl / (gms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": round(gfl / (gms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
         # the HBM-bound streaming KV-cache kernel is the one north_star singles out: always report it too
         t = rows.get("tattn_stream_kernel")
         if t:

@@ -10,6 +10,7 @@ typedef h16 __attribute__((ext_vector_type(2))) h16x2;
 typedef h16 __attribute__((ext_vector_type(4))) h16x4;
 typedef h16 __attribute__((ext_vector_type(8))) h16x8;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
 
 #define L2D_WAVE 64
 

@@ -82,7 +82,10 @@ __device__ __forceinline__ float rg_row_sum(float v, bool wide) {
 }
 
 template <int RD, int SK>
-constexpr int rg_ring() { return SK > 0 ? (RD < SK ? RD : SK) : 4; }
+constexpr int rg_ring() {
+    // K = 1280 rows are normalised through LDS (two passes) and carry more live state: a 24-deep ring spills there, 16 does not
+    return SK > 0 ? ((SK >= 80 && RD > 16) ? 16 : (RD < SK ? RD : SK)) : 4;
+}
 
 // main loop + epilogue.  SK = number of 16-wide k steps when known at compile time (K = 320 / 640 / 1280), 0 = runtime K
 // (any K % 64 == 0: groups of 4 k steps, double-buffered; the compiler drains the loads at the loop back-edge, i.e. one

@@ -488,7 +488,7 @@ int l2d_launch_tattn_stream(const l2d_op *op, hipStream_t s) {
     // LDS-DMA ring kernel (tattn_ring.hip): the default wherever it applies (1.00 vs 1.33 ms per cfg-2 frame)
     if (a.variant == 13 || (a.variant == 0 && l2d_tattn_ring_ok(a, op->p[9]))) {
         if (!l2d_tattn_ring_ok(a, op->p[9])) {
-            l2d_set_error("tattn_stream(tag %d): ring variant needs C in {320,640,1280}, L in {12,16}, T %% 8 == 0, p9 = zero page", op->tag);
+            l2d_set_error("tattn_stream(tag %d): ring variant needs C in {320,640,1280}, L in {12,16,24,40}, T %% 8 == 0, p9 = zero page", op->tag);
             return L2D_EINVAL;
         }
         rc = l2d_launch_tattn_ring(a, op->p[9], s);

@@ -469,6 +469,237 @@ __global__ __launch_bounds__(320 + 64 * NLW) void tattn_stream_ringlw_kernel(TAt
     }
 }
 
+// Long windows (L = 40: cfg-5, 17 GB of cache per frame).  The kernels above keep a row's L scores in registers across a
+// fully unrolled stage loop (2 L / R stages): at L = 40 that loop is 40 stages long, hipcc stops unrolling it and the score
+// array lands in scratch (176 bytes per lane; measured 2.0 TB/s, below the old chunked kernel).  Here the stage loops are
+// ordinary loops: the partial scores of a row go straight into the thread's LDS score row, the L-wide softmax runs once on
+// registers between the K and the V stages, and the probabilities are written back to the thread's own score row, from where
+// the V stages read them -- two block barriers per pixel group instead of one, everything else (loader wave, ring, DMA
+// images, rounding points) as above.  The gathered PE rows and the score rows leave 50 KB for the ring: 5 stages of 2 rows.
+template <int HG, int L, int R, int NS>
+__global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
+    constexpr int PB = 8, TP = 40, NT = TP * PB, NSTG = 2 * L / R, LPSL = 5 * R;
+    constexpr int STAGE_H = R * PB * TP * 8;
+    constexpr int LP = L + 4;
+    static_assert((NS - 2) * LPSL < 64 && L % 4 == 0 && L % R == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+    h16 *ring = reinterpret_cast<h16 *>(ring_raw);
+    float *sp = reinterpret_cast<float *>(ring_raw + (size_t)NS * STAGE_H * sizeof(h16));
+    float *blds = sp + NT * LP;
+    h16 *kpl = reinterpret_cast<h16 *>(blds + L);
+    h16 *vpl = kpl + L * 320;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C, CH = C / 320;
+    const int bpu = (groups_per_unit + gpb - 1) / gpb;
+    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x / bpu);
+    const int n = __builtin_amdgcn_readfirstlane(unit / CH);
+    const int chunk = unit - n * CH;
+    const int g0 = (blockIdx.x - unit * bpu) * gpb;
+    const int ng = min(gpb, groups_per_unit - g0);
+    const long long slab = (long long)a.T * L * C;
+    h16 *kbase = a.cache + (long long)n * 2 * slab + (long long)g0 * PB * L * C + chunk * 320;
+    h16 *vbase = kbase + slab;
+    const h16 *qkv_b = a.qkv + ((long long)n * a.T + g0 * PB) * 3 * C + chunk * 320;
+    h16 *out_b = a.out + ((long long)n * a.T + g0 * PB) * C + chunk * 320;
+    const int u = __builtin_amdgcn_readfirstlane((int)a.update_idx[n]);
+    const long long *pei = a.pe_idx + (long long)n * L;
+    const h16 *bi = a.bias + (long long)n * L;
+    const int total = ng * NSTG;
+
+    if (wave == 5) {
+        // ---------------------------------------------------------------- the loader wave
+        const int lane = tid & 63;
+        unsigned long long live = 0;
+        for (int l = 0; l < L; ++l)
+            if ((float)bi[l] > -1e30f && l != u) live |= 1ull << l;
+        live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(live >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(live & 0xffffffffull));
+        unsigned coff[5], qoff[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int v = k * 64 + lane, p = v / TP, cc = v - p * TP;
+            coff[k] = (unsigned)(p * L * C + cc * 8);
+            qoff[k] = (unsigned)(p * 3 * C + cc * 8);
+        }
+        int it_issue = 0, is_s = 0, is_slot = 0, is_g = 0;
+        auto issue = [&]() {
+            const bool isv = is_s >= NSTG / 2;
+            const int l0 = (isv ? is_s - NSTG / 2 : is_s) * R;
+            const h16 *cb = (isv ? vbase : kbase) + (long long)is_g * (PB * L * C);
+            const h16 *qb = qkv_b + (long long)is_g * (PB * 3 * C) + (isv ? 2 * C : C);
+            h16 *dst = ring + is_slot * STAGE_H;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int l = l0 + j;
+                const unsigned long long lv = 0ull - ((live >> l) & 1ull);
+                const unsigned long long nw = (0ull - (unsigned long long)(l == u ? 1u : 0u)) & ~lv;
+                const unsigned long long sb = ((unsigned long long)(cb + l * C) & lv) | ((unsigned long long)qb & nw) |
+                                              ((unsigned long long)zero & ~(lv | nw));
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const unsigned vo = (coff[k] & (unsigned)lv) | (qoff[k] & (unsigned)nw);
+                    __builtin_amdgcn_global_load_lds(L2D_GPTR(reinterpret_cast<const h16 *>(sb) + vo), L2D_LPTR(dst + j * NT * 8 + k * 512), 16, 0, 0);
+                }
+            }
+            ++it_issue;
+            if (++is_s == NSTG) { is_s = 0; ++is_g; }
+            is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
+        };
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (it_issue < total) issue();
+        int it = 0;
+        for (int gi = 0; gi < ng; ++gi) {
+#pragma unroll 1
+            for (int s = 0; s < NSTG; ++s) {
+                if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPSL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (it_issue < total) issue();
+                if (s == NSTG / 2 - 1) {                     // the consumers' two softmax barriers
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+                }
+                ++it;
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumers
+    const int p = tid / TP, cc = tid - p * TP;
+    const unsigned coff = (unsigned)(p * L * C + cc * 8);
+    const unsigned qoff = (unsigned)(p * 3 * C + cc * 8);
+    const unsigned ooff = (unsigned)(p * C + cc * 8);
+    if (tid < L) blds[tid] = (float)bi[tid];
+    for (int f0 = 0; f0 < L * TP; f0 += NT) {
+        const int f = f0 + tid;
+        if (f < L * TP) {
+            const int l = f / TP, c = f - l * TP;
+            const long long po = pei[l] * C + chunk * 320 + c * 8;
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.k_pe + po), L2D_LPTR(kpl + (f0 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.v_pe + po), L2D_LPTR(vpl + (f0 + wave * 64) * 8), 16, 0, 0);
+        }
+    }
+    const h16x8 qpe = l2d_ld8(a.q_pe + pei[u] * C + chunk * 320 + cc * 8);
+    h16x8 qn = l2d_ld8(qkv_b + qoff);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's PE-row DMAs have landed before the first barrier publishes them
+
+    const float scale = rsqrtf((float)(C / a.H));
+    const int gs = p * TP + (cc / HG) * HG;
+    float *row = sp + tid * LP;
+    const h16 *kpt = kpl + cc * 8, *vpt = vpl + cc * 8;
+    int cs_slot = 0;
+    for (int gi = 0; gi < ng; ++gi) {
+        const h16x8 q8 = qn + qpe;
+        h16 *ku = kbase + (long long)gi * (PB * L * C) + u * C;
+        // ---- K stages: partial scores of this thread's 8 channels -> its LDS score row
+#pragma unroll 1
+        for (int s = 0; s < NSTG / 2; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
+            float d[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int l = s * R + r;
+                h16x8 kk = l2d_ld8(st + r * NT * 8);
+                if (l == u) l2d_st8(ku + coff, kk);
+                kk = kk + l2d_ld8(kpt + l * 320);
+                d[r] = ring_dot8(q8, kk);
+            }
+            if constexpr (R == 2) *reinterpret_cast<f32x2 *>(row + s * 2) = (f32x2){d[0], d[1]};
+            else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) row[s * R + r] = d[r];
+            }
+            cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
+        }
+        // ---- per-head reduction over the HG threads of a head + the 1 x L softmax, on registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float sc[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) sc[l] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < HG; ++j) {
+            const float *rr = sp + (gs + j) * LP;
+#pragma unroll
+            for (int l = 0; l < L; l += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(rr + l);
+                sc[l] += x[0]; sc[l + 1] += x[1]; sc[l + 2] += x[2]; sc[l + 3] += x[3];
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int l = 0; l < L; l += 4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(blds + l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[l + e] = sc[l + e] * scale + b4[e]; mx = fmaxf(mx, sc[l + e]); }
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) { sc[l] = __expf(sc[l] - mx); den += sc[l]; }
+        const float inv = 1.0f / den;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every thread has read the partial rows: they may be overwritten
+#pragma unroll
+        for (int l = 0; l < L; l += 4) *reinterpret_cast<f32x4 *>(row + l) = (f32x4){sc[l] * inv, sc[l + 1] * inv, sc[l + 2] * inv, sc[l + 3] * inv};
+        if (gi + 1 < ng) qn = l2d_ld8(qkv_b + (long long)(gi + 1) * (PB * 3 * C) + qoff);
+        // ---- V stages: probabilities from the thread's own score row
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < NSTG / 2; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
+            float pr[R];
+            if constexpr (R == 2) { const f32x2 t = *reinterpret_cast<const f32x2 *>(row + s * 2); pr[0] = t[0]; pr[1] = t[1]; }
+            else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) pr[r] = row[s * R + r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int l = s * R + r;
+                h16x8 vv = l2d_ld8(st + r * NT * 8);
+                if (l == u) l2d_st8(ku + slab + coff, vv);
+                vv = vv + l2d_ld8(vpt + l * 320);
+                ring_axpy8(o, pr[r], vv);
+            }
+            cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
+        }
+        h16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
+        l2d_st8(out_b + (long long)gi * (PB * C) + ooff, ov);
+    }
+}
+
+template <int L, int HG, int R, int NS>
+static void launch_ringlw_long(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
+    constexpr int NT = 320;
+    constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
+    static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)tattn_stream_ringlw_long_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+            attr_done = true;
+        else
+            (void)hipGetLastError();
+    }
+    const int CH = a.C / 320;
+    const int groups_per_unit = a.T / 8;
+    const int total = a.N * CH * groups_per_unit;
+    const int gpb = (total + slots - 1) / slots;
+    const int bpu = (groups_per_unit + gpb - 1) / gpb;
+    hipLaunchKernelGGL((tattn_stream_ringlw_long_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(384), LDS, s, a, zero, gpb, groups_per_unit);
+}
+
 template <int L, int HG, int R, int NS, int NLW = 1>
 static void launch_ringlw(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
     constexpr int NT = 320;
@@ -542,12 +773,12 @@ static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_
         else if (g == 5) launch_ringlw<L, HG, 4, 4, 2>(a, zero, cus, s);
         else launch_ringlw<L, HG, 4, 4, 1>(a, zero, cus, s);
     } else {
-        launch_ring_g<L, HG, 2, 5, 8>(a, zero, cus, s);
+        launch_ringlw_long<L, HG, 2, 5>(a, zero, cus, s);
     }
 }
 
 bool l2d_tattn_ring_ok(const TAttnArgs &a, const void *zero) {
-    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12 || a.L == 24) && (a.T % 8 == 0) && a.H == 8;
+    return zero && (a.C == 320 || a.C == 640 || a.C == 1280) && (a.L == 16 || a.L == 12 || a.L == 24 || a.L == 40) && (a.T % 8 == 0) && a.H == 8;
 }
 
 int l2d_launch_tattn_ring(const TAttnArgs &a, const void *zero_page, hipStream_t s) {

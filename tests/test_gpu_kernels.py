@@ -432,7 +432,10 @@ def _tattn_case(C, T, Lw, S, N, seed, ramp=True):
                                                 # chunked kernel's real shapes (T = a slice of the 64x96 / 72x128 levels)
                                                 (320, 384, 24, 8, 2, 0), (640, 96, 24, 8, 2, 0), (1280, 24, 24, 8, 2, 0),
                                                 (320, 144, 40, 8, 2, 0), (640, 36, 40, 8, 2, 0), (1280, 9, 40, 8, 2, 0),
-                                                (320, 100, 24, 8, 4, 3), (640, 50, 40, 8, 2, 3)])
+                                                (320, 100, 24, 8, 4, 3), (640, 50, 40, 8, 2, 3),
+                                                # L = 40 through the loader-wave ring kernel's long-window form (scores in LDS)
+                                                (320, 1152, 40, 8, 2, 13), (640, 72, 40, 8, 2, 13), (1280, 16, 40, 8, 1, 13),
+                                                (320, 144, 40, 8, 3, 13), (320, 384, 24, 8, 2, 13)])
 def test_tattn_stream(L, C, T, Lw, S, N, variant):
     from live2diff_amd.config import tiny_config
     from oracle import unet_ref as O

@@ -38,7 +38,16 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     # known and accepted: the round-1 register-staged flash kernel at d = 160 (variant 1, kept for A/B only; the default ring
     # kernel covers d = 160) needs 100 bytes of scratch
     legacy = {"_Z20flash_attn_kernel_w2ILi160EEv6FAArgs"}
-    bad = {n: k for n, k in kernels.items() if (k["vgpr_spill_count"] or k["private_segment_fixed_size"]) and n not in legacy}
+    # the runtime-K form of the token-resident GEMM (template SK = 0: unit-test widths and K = 768 only -- the SD-1.5 widths
+    # 320 / 640 / 1280 take the straight-line SK = 20 / 40 / 80 forms, which must be clean): 68 bytes of scratch, no VGPR spills
+    generic_k = re.compile(r"rowgemm_kernelILi\dELi\dELi\d+ELi0ELi\d+E")
+    bad = {}
+    for n, k in kernels.items():
+        if n in legacy or not (k["vgpr_spill_count"] or k["private_segment_fixed_size"]):
+            continue
+        if generic_k.search(n) and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] <= 128:
+            continue
+        bad[n] = k
     assert not bad, bad
 
 
@@ -61,5 +70,17 @@ def test_occupancy_budgets(kernels):
     for n, k in pick(r"flash_ring_kernelILi(40|80)ELi1ELi4ELi0E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
     # KV-cache ring kernel: 5 waves per block, one block per CU (10 waves with the 16-pixel geometry: three on two SIMDs)
-    for n, k in pick(r"tattn_stream_ring_kernel").items():
+    # (L = 24: one block of 5 / 6 waves per CU = at most two waves per SIMD, so up to 256 registers cost nothing)
+    for n, k in pick(r"tattn_stream_ring(lw)?_kernelILi\d+ELi(12|16)E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
+    for n, k in pick(r"tattn_stream_ring(lw)?_kernelILi\d+ELi24E").items():
+        assert k["vgpr_count"] + k["agpr_count"] <= 256, (n, k)
+    # long-window loader-wave form (L = 40): no scratch -- the fully unrolled form's score array went to scratch there, and a
+    # scratch load would also break the loader's counted vmcnt
+    lw = pick(r"tattn_stream_ringlw_long_kernel")
+    assert len(lw) == 3, sorted(lw)
+    for n, k in lw.items():
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] + k["agpr_count"] <= 128, (n, k)
+    # token-resident GEMM, compile-time K: the geometries with up to 8 waves per block rely on <= 256 registers, no spills
+    for n, k in pick(r"rowgemm_kernelILi\dELi\dELi\d+ELi(20|40|80)E").items():
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)

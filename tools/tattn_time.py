@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--denoise-steps", type=int, default=2)
     ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--variant", type=int, default=0, help="0 auto (ring where it applies), 2 chunked kernel, 13 ring forced")
     a = ap.parse_args()
     from live2diff_amd import _lib, ops
     from live2diff_amd.config import motion_module_layout, sd15_config
@@ -34,12 +35,12 @@ def main():
         qkv = torch.randn(N * T, 3 * C, device=dev, generator=g, dtype=torch.float16)
         pe = [torch.randn(L, C, device=dev, generator=g, dtype=torch.float16) for _ in range(3)]
         out = torch.empty(N * T, C, device=dev, dtype=torch.float16)
-        pl.append(*ops.tattn_stream(qkv, cache, pe[0], pe[1], pe[2], pe_idx, upd, bias, out, N=N, T=T, C=C, L=L, H=8))
+        pl.append(*ops.tattn_stream(qkv, cache, pe[0], pe[1], pe[2], pe_idx, upd, bias, out, N=N, T=T, C=C, L=L, H=8, variant=a.variant))
         byts += 4 * N * T * L * C + 8 * N * T * C
     pl.run()
     torch.cuda.synchronize()
     ms = min(pl.time_ms(5) for _ in range(3))
-    print(json.dumps({"L2D_TATTN_RING": os.environ.get("L2D_TATTN_RING", ""), "window": L, "launches": len(pl), "ms_per_frame": round(ms, 4),
+    print(json.dumps({"L2D_TATTN_RING": os.environ.get("L2D_TATTN_RING", ""), "window": L, "variant": a.variant, "launches": len(pl), "ms_per_frame": round(ms, 4),
                       "GBps": round(byts / ms / 1e6, 1), "frac_of_8TBps": round(byts / ms / 1e6 / 8000, 4)}))
 
 
