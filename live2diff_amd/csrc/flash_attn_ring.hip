@@ -439,358 +439,11 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Software-pipelined variant (geometry 6; 4 waves x 32 query rows, d <= 40): the QK^T MFMAs of tile t+1 are issued in the
-// same straight-line region as the softmax (row maximum, v_exp_f32, packing) of tile t, so that ONE wave keeps the matrix pipe
-// busy under its own VALU work instead of relying on the second resident wave.  Why it matters here: at d = 40 a wave's tile
-// costs 448 MFMA cycles but ~700 VALU cycles (32 quarter-rate v_exp_f32 per lane = 512 cycles alone), and the in-order
-// stream of the plain kernel leaves a wave stalled ~55 % of the time (PMC: 43 % issuing).  Two score tiles are live at once
-// (64 VGPRs); the loop is unrolled by two so that they swap roles without register moves.  Ring bookkeeping differs from the
-// plain kernel in one point: iteration t reads K of tile t+1 and V^T of tile t, so tile t+1 must have landed at the top of
-// iteration t -- one more ring stage (NS = 5) keeps the same number of tiles in flight.
-// MEASURED (profiles/r3l_flash_pipe_time.txt, same process): parity-green, but 95.6 vs 80.9 us at T = 4096 (6144: 196 vs 179,
-// 9216: 426 vs 393) -- NOT the default.  The interleave works as intended (ISA: 16 x {MFMA, 2 v_exp, 1 VALU}, 12 x {MFMA, 4
-// VALU}), which is exactly what shows the real bound: the SIMD's VALU, not the matrix pipe.  Per wave and 64-key tile the
-// softmax needs 32 quarter-rate v_exp_f32 (512 cycles) + ~120 other VALU instructions (480) against 448 MFMA cycles, and the
-// two resident waves share ONE VALU: ~2 000 VALU cycles per tile pair = 53 us for this shape however the stream is ordered;
-// the exponentials alone (2.7e8 of them at 4 per cycle and SIMD) are 27 us.  0.40 of the MFMA peak would be 43 us.  Stretching
-// one wave's MFMAs over its own VALU work only lengthens its critical path; the plain kernel lets the OTHER wave's MFMAs run
-// under it.  What would move this kernel is fewer VALU instructions per score, not more overlap.
-template <int D, int NW>
-__device__ __forceinline__ void flash_ring_body_pipe(const FARArgs &a) {
-    constexpr int QS = 2;
-    using Cf = FARCfg<D, NW, 5>;
-    constexpr int KK = Cf::KK, D16 = Cf::D16, NS = Cf::NS, LPS = Cf::LPS, VPW = Cf::VPW, NVI = Cf::NVI;
-    constexpr int KPW = Cf::KPW, NKI = Cf::NKI, NT = 64 * NW;
-    constexpr int STAGE_H = Cf::STAGE / 2, KH = Cf::KBYTES / 2;      // halfs
-    static_assert(KK <= 2 && D16 <= 3, "register budget of the pipelined flash kernel");
-    extern __shared__ __attribute__((aligned(16))) h16 smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    const int nqb = (a.Tq + 16 * NW * QS - 1) / (16 * NW * QS);
-    int wgid;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        wgid = a.xcd ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : (int)blockIdx.x;
-    }
-    const int bh = wgid / nqb, qb = wgid - bh * nqb;
-    const int b = bh / a.H, h = bh - b * a.H;
-    const int q0 = qb * (16 * NW * QS) + wave * (16 * QS);
-    const h16 *qp = a.q + (long long)b * a.sq + h * D;
-    const h16 *kp = a.k + (long long)b * a.sk + h * D;
-    const h16 *vp = a.vt + (long long)b * a.svt + (long long)h * D * a.ldvt;
-    h16 *op = a.out + (long long)b * a.so + h * D;
-    const int nt = (a.Tk + 63) / 64;
-
-    {   // static LDS content: zeros (padding), ones in V^T row D of every stage
-        const h16x8 z = l2d_zero8();
-        for (int i = tid; i < (Cf::LDS / 16); i += NT) l2d_st8(smem + i * 8, z);
-        if (Cf::ONES) {
-            __syncthreads();
-            h16x8 one;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) one[e] = (h16)1.0f;
-            if (tid < NS * 8) l2d_st8(smem + (tid >> 3) * STAGE_H + KH + D * 64 + (tid & 7) * 8, one);
-        }
-    }
-    const float c2e = rsqrtf((float)D) * 1.4426950408889634f;
-    h16x8 qf[QS][KK];
-    {
-        h16x8 sc;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sc[e] = (h16)c2e;
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const int qr = q0 + qs * 16 + li, dc = kk * 32 + lg * 8;
-                qf[qs][kk] = (qr < a.Tq && dc < D) ? l2d_ld8(qp + (long long)qr * a.ldq + dc) * sc : l2d_zero8();
-            }
-    }
-    // DMA descriptors: identical to flash_ring_body (see there for the key permutation and the swizzles)
-    const int krow = (wave & 3) * 16 + (lane >> 2);
-    const int kcol = (((lane & 3) ^ ((krow >> 1) & 3)) << 3);
-    const int kkey = (krow & 32) | (((krow >> 2) & 3) << 3) | (((krow >> 4) & 1) << 2) | (krow & 3);
-    int vrow[VPW], vkey[VPW];
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-        const int j = wave + NW * i;
-        vrow[i] = j * 8 + (lane >> 3);
-        vkey[i] = (((lane & 7) ^ ((vrow[i] >> 1) & 7)) << 3);
-    }
-    h16 *dummy = smem + NS * STAGE_H;
-    const h16 *kptr[KPW];
-    long long kadv[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int pc = wave + NW * i, kk = pc >> 2;
-        const bool real = pc < NKI && kk * 32 + kcol < D;
-        kptr[i] = real ? kp + (long long)kkey * a.ldk + kk * 32 + kcol : a.zero;
-        kadv[i] = real ? 64ll * a.ldk : 0ll;
-    }
-    const h16 *vptr[VPW];
-    long long vadv[VPW];
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-        const bool real = (wave + NW * i) < NVI && vrow[i] < D;
-        vptr[i] = real ? vp + (long long)vrow[i] * a.ldvt + vkey[i] : a.zero;
-        vadv[i] = real ? 64ll : 0ll;
-    }
-    int is_slot = 0, is_key0 = 0, is_tile = 0;
-    auto issue = [&]() {                                                  // LPS DMA wave-instructions, always
-        const bool last = (is_tile == nt - 1);                            // wave-uniform; only the last tile can reach beyond Tk
-        h16 *st = smem + is_slot * STAGE_H;
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int pc = wave + NW * i;
-            const h16 *src = (last && is_key0 + kkey >= a.Tk) ? a.zero : kptr[i];
-            h16 *dst = pc < NKI ? st + (pc >> 2) * 2048 + (pc & 3) * 512 : dummy;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
-            kptr[i] += kadv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VPW; ++i) {
-            const int j = wave + NW * i;
-            const h16 *src = (last && is_key0 + vkey[i] >= a.Tk) ? a.zero : vptr[i];
-            h16 *dst = j < NVI ? st + KH + j * 512 : dummy;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
-            vptr[i] += vadv[i];
-        }
-        is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
-        is_key0 += 64;
-        ++is_tile;
-    };
-    const int kswz = (li >> 1) & 3, vswz = (li >> 1) & 7;
-    const int koff = li * 32 + ((lg ^ kswz) << 3);
-    int voff[2];
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) voff[c2] = KH + li * 64 + (((c2 * 4 + lg) ^ vswz) << 3);
-
-    f32x4 oacc[D16][QS];
-#pragma unroll
-    for (int ds = 0; ds < D16; ++ds)
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) oacc[ds][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mref[QS], lrow[QS];
-    f32x4 cinit[QS];
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) { mref[qs] = 0.f; lrow[qs] = 0.f; cinit[qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    float mx[QS];                                                         // row maxima of the CURRENT tile's scores (vs mref)
-    auto row_max = [&](f32x4 (&sc)[4][QS]) {
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            float m = fmaxf(fmaxf(sc[0][qs][0], sc[0][qs][1]), fmaxf(sc[0][qs][2], sc[0][qs][3]));
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks)
-                m = fmaxf(fmaxf(m, fmaxf(sc[ks][qs][0], sc[ks][qs][1])), fmaxf(sc[ks][qs][2], sc[ks][qs][3]));
-            mx[qs] = far_row_max(m);
-        }
-    };
-    auto mask_last = [&](f32x4 (&sc)[4][QS], int t) {                     // (only for the last tile when Tk % 64 != 0)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if ((t * 64 + (ks >> 1) * 32 + lg * 8 + (ks & 1) * 4 + r) >= a.Tk) sc[ks][qs][r] = -3.0e38f;
-    };
-    // A: raise the reference (rare after the first tile).  Runs BEFORE the next tile's QK^T is issued, so only O, l and the
-    // current tile's scores are at the old reference.
-    auto rescale = [&](f32x4 (&cur)[4][QS], bool first) {
-        if (first || __builtin_expect(__any(fmaxf(mx[0], mx[1]) > 8.0f), 0)) {
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int qs = 0; qs < QS; ++qs) {
-                const float delta = first ? mx[qs] : fmaxf(mx[qs], 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                mref[qs] += delta;
-                lrow[qs] *= alpha;
-#pragma unroll
-                for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) cur[ks][qs] -= delta;
-                cinit[qs] = (f32x4){-mref[qs], -mref[qs], -mref[qs], -mref[qs]};
-            }
-        }
-    };
-    // B + C, ONE scheduling region in the steady state: QK^T of tile t+1 (16 MFMAs) under exp / pack of tile t's scores, then
-    // PV of tile t (4 * D16 MFMAs) under the row maximum of tile t+1.  The sched_group_barrier sequence asks for "one MFMA,
-    // then a few VALU / transcendental instructions" so that the in-order stream never parks on a busy matrix pipe.
-    auto step = [&](f32x4 (&cur)[4][QS], f32x4 (&nxt)[4][QS], int t, auto next_tag, auto mask_tag) {
-        constexpr bool NEXT = decltype(next_tag)::value, MASK = decltype(mask_tag)::value;
-        const h16 *st = smem + (t % NS) * STAGE_H;
-        const h16 *sn = smem + ((t + 1) % NS) * STAGE_H;
-        h16x8 kf[KK][4], vf[2][D16];
-        if (NEXT) {
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[kk][ks] = l2d_ld8(sn + kk * 2048 + ks * 512 + koff);
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-            for (int ds = 0; ds < D16; ++ds) vf[c2][ds] = l2d_ld8(st + ds * 1024 + voff[c2]);
-        if (NEXT) {
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        nxt[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk][ks], qf[qs][kk], kk == 0 ? cinit[qs] : nxt[ks][qs], 0, 0, 0);
-        }
-        h16x8 pf[2][QS];
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
-            float psum = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(cur[ks][qs][r]);
-                    if (!Cf::ONES) psum += pv;
-                    pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
-                }
-            if (!Cf::ONES) lrow[qs] += psum;
-        }
-        if (NEXT) {
-#pragma unroll
-            for (int i = 0; i < KK * QS * 4; ++i) {                       // (KK * 8 MFMAs, 32 v_exp_f32 + 16 packs to place)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, KK == 2 ? 2 : 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, KK == 2 ? 1 : 2, 0);
-            }
-        }
-        if (MASK) mask_last(nxt, t + 1);
-#pragma unroll
-        for (int qs = 0; qs < QS; ++qs)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                for (int ds = 0; ds < D16; ++ds)
-                    oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][ds], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
-        if (NEXT) {
-            row_max(nxt);
-            if (!MASK) {
-#pragma unroll
-                for (int i = 0; i < 4 * D16; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                }
-            }
-        }
-    };
-    auto scrub_last = [&]() {                                             // see flash_ring_body
-        const int first = a.Tk & 63, last = ((a.Tk + 7) & ~7) & 63;
-        if ((a.Tk & 7) == 0) return;
-        h16 *vs = smem + ((nt - 1) % NS) * STAGE_H + KH;
-        for (int r = tid; r < D; r += NT) {
-            const int sw = (r >> 1) & 7;
-            for (int c = first; c < (last == 0 ? 64 : last); ++c) vs[r * 64 + ((((c >> 3) ^ sw)) << 3) + (c & 7)] = (h16)0.0f;
-        }
-        __syncthreads();
-    };
-
-    __syncthreads();                                                      // static LDS content in place before any DMA lands
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nt) issue();
-    f32x4 sa[4][QS], sb[4][QS];
-    // tile 0's scores and their row maxima (nothing to overlap with yet)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-        const h16 *st = smem;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h16x8 k1 = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
-#pragma unroll
-                for (int qs = 0; qs < QS; ++qs)
-                    sa[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qs][kk], kk == 0 ? cinit[qs] : sa[ks][qs], 0, 0, 0);
-            }
-        if (nt == 1 && (a.Tk & 63) != 0) mask_last(sa, 0);
-        row_max(sa);
-    }
-    // Iteration t reads K of tile t+1 and V^T of tile t.  Its top barrier = every wave finished iteration t-1, so the slot of
-    // tile t-1 is free for tile t-1+NS; each wave has waited for its own share of tile t+1, so after the barrier the whole
-    // tile is in LDS.  In flight behind it: tiles t+2 .. t+NS-2, i.e. (NS-3) * LPS wave-instructions per wave.
-    const bool ragged = (a.Tk & 63) != 0;
-    auto top = [&](int t) {
-        if (is_tile - 1 - (t + 1) >= NS - 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tail of the sequence: everything has been issued
-        __builtin_amdgcn_s_barrier();
-        if (t >= 1 && is_tile < nt) issue();                               // refills the slot of tile t-1
-    };
-    auto iter = [&](f32x4 (&cur)[4][QS], f32x4 (&nxt)[4][QS], int t) {
-        top(t);
-        rescale(cur, t == 0);
-        if (t + 2 < nt) {
-            step(cur, nxt, t, T_{}, F_{});
-        } else if (t + 1 < nt) {                                           // the next tile is the last one
-            if (ragged) step(cur, nxt, t, T_{}, T_{});
-            else step(cur, nxt, t, T_{}, F_{});
-        } else {
-            scrub_last();
-            step(cur, nxt, t, F_{}, F_{});
-        }
-    };
-    for (int t = 0; t < nt; t += 2) {
-        iter(sa, sb, t);
-        if (t + 1 < nt) iter(sb, sa, t + 1);
-    }
-
-#pragma unroll
-    for (int qs = 0; qs < QS; ++qs) {
-        float l;
-        if (Cf::ONES) {
-            l = __shfl(oacc[D / 16][qs][D % 4], ((D % 16) / 4) * 16 + li, 64);
-        } else {
-            l = lrow[qs];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
-        }
-        const float inv = 1.0f / l;
-        const int qr = q0 + qs * 16 + li;
-        if (qr >= a.Tq) continue;
-#pragma unroll
-        for (int ds = 0; ds < D16; ++ds) {
-            const int dc = ds * 16 + lg * 4;
-            if (dc >= D) continue;
-            h16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (h16)(oacc[ds][qs][r] * inv);
-            *reinterpret_cast<h16x4 *>(op + (long long)qr * a.ldo + dc) = o;
-        }
-    }
-}
-
-template <int D, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_ring_pipe_kernel(FARArgs a) {
-    flash_ring_body_pipe<D, NW>(a);
-}
-
-template <int D>
-static int launch_far_pipe(const FARArgs &a, hipStream_t s) {
-    using Cf = FARCfg<D, 4, 5>;
-    static bool attr_done = false;
-    if (Cf::LDS > 65536 && !attr_done) {
-        if (hipFuncSetAttribute((const void *)flash_ring_pipe_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
-            attr_done = true;
-        else
-            (void)hipGetLastError();
-    }
-    dim3 grid(((a.Tq + 127) / 128) * a.H * a.B);
-    hipLaunchKernelGGL((flash_ring_pipe_kernel<D, 4>), grid, dim3(256), Cf::LDS, s, a);
-    return L2D_OK;
-}
+// Removed in round 3 (negative results, recorded in DESIGN.md section 3.2 with their profiles): a software-pipelined body that
+// issued the QK^T MFMAs of tile t+1 inside the softmax of tile t (parity-green, 95.6 vs 80.9 us at T = 4096, d = 40,
+// profiles/r3l_flash_pipe_time.txt: the bound is the SIMD's shared VALU -- 32 quarter-rate v_exp_f32 + ~120 VALU instructions
+// against 448 MFMA cycles per wave and 64-key tile -- so stretching one wave's MFMAs over its own VALU work only lengthened its
+// critical path), 8 waves x 16 rows and a 2-deep ring with 4-5 blocks per CU (81.0 / 90.1 vs 81.0 us).
 
 // NW waves x (16 * QS) queries per block.  The SIMD issues at most one VALU and one MFMA per 4 cycles, from DIFFERENT
 // waves: with two waves per SIMD the in-order streams (28 MFMA + ~140 VALU + waits per wave and tile at d = 40) leave both
@@ -818,8 +471,7 @@ static int launch_far_q(const FARArgs &a, hipStream_t s) {
     return L2D_OK;
 }
 
-// geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows; 4 = 8 waves x 16 rows (d <= 40); 5 = 4 waves x 16 rows with a
-// 2-deep ring (4-5 blocks per CU); 6 = 4 waves x 32 rows, software-pipelined across key tiles (d <= 40)
+// geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows
 template <int D>
 static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
     if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
@@ -830,15 +482,10 @@ static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
             const char *e = getenv("L2D_FLASH_GEO");
             forced = e ? atoi(e) : 0;
         }
-        if (forced >= 2 && forced <= 6 && big >= 384) geo = forced;
+        if (forced >= 2 && forced <= 3 && big >= 384) geo = forced;
     }
     if constexpr (D <= 80) {          // d = 160 with 32 query rows per wave does not fit the register file
         if (geo == 2) return launch_far_q<D, 2, 4, 0>(a, s);
-    }
-    if constexpr (D <= 40) {
-        if (geo == 4) return launch_far_q<D, 1, 8, 0>(a, s);
-        if (geo == 5) return launch_far_q<D, 1, 4, 2>(a, s);
-        if (geo == 6) return launch_far_pipe<D>(a, s);
     }
     return launch_far_q<D, 1, 4, 0>(a, s);
 }

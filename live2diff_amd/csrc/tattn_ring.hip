@@ -69,14 +69,13 @@ __device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
     }
 }
 
-// HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) = 100 KB of ring, one block per CU;
-// (2, 3) = 30 KB, TWO blocks per CU (76 KB each): ten waves instead of five on the CU's four SIMDs (the loop is issue bound on
-// the SIMD that hosts two of a block's five waves) and one block's DMA under the other's arithmetic.
-// PB = pixels per group = 8 (320 threads, 5 waves) or 16 (640 threads, 10 waves: 3/3/2/2 over the four SIMDs instead of
-// 2/1/1/1 -- the loop is instruction-issue bound on the fullest SIMD, tools/kv_pattern_probe.py shows the DMA side alone at
-// 6.2 TB/s).  Everything per pixel is unchanged; the stage (R rows x PB pixels), the score rows and the DMA images scale with
-// the block size NT = 40 PB, the PE rows and the per-row constants are shared.
-template <int HG, int L, int R, int NS, int PB, bool ILV>
+// Round-2 form, kept as the A/B partner of the loader-wave kernels below (L2D_TATTN_RING=4) and as the carrier of the
+// in-kernel stage stamps (tools/tattn_probe.py): every one of the five waves issues its own share of a stage's refill and then
+// does the stage's arithmetic.  HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) =
+// 100 KB of ring, one block of PB = 8 pixels x 40 threads per CU.  Geometries that were measured and removed again (round 2 /
+// round 3, profiles/r2l*, r3e_*): (2 rows, 3 stages) with two blocks per CU (10 % slower), 16-pixel / 10-wave blocks (equal),
+// refill DMAs interleaved row by row with the arithmetic (2.7 % slower).
+template <int HG, int L, int R, int NS, int PB>
 __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
     constexpr int TP = 40, NT = TP * PB, NSTG = 2 * L / R, LPS = R;
     constexpr int STAGE_H = R * PB * TP * 8;       // halfs per stage (20 KB at R = 4, PB = 8)
@@ -138,10 +137,9 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
     // ---- DMA side
     const int total = ng * NSTG;
     int it_issue = 0, is_s = 0, is_slot = 0, is_g = 0;
-    // one refill = LPS row DMAs + the bookkeeping; issue_row(j) can be called between the rows' arithmetic of the stage that
-    // is being consumed (ILV): a `global_load_lds` wave-instruction takes ~200 cycles to issue in this kernel
-    // (profiles/r3r_tattn_stage_phases.txt), four of them back to back in front of the arithmetic made a stage the SUM of refill
-    // issue and arithmetic; interleaved, the memory pipe drains one row request while the VALU works on another row
+    // one refill = LPS row DMAs + the bookkeeping.  A `global_load_lds` wave-instruction takes ~200 cycles to issue in this
+    // kernel (profiles/r3r_tattn_stage_phases.txt): four of them in front of the arithmetic make a stage the SUM of refill issue
+    // and arithmetic -- which is what the loader-wave form below removes
     auto issue_row = [&](int j) {
         const bool isv = is_s >= NSTG / 2;
         const int l0 = (isv ? is_s - NSTG / 2 : is_s) * R;
@@ -201,20 +199,18 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
             __builtin_amdgcn_s_barrier();
             TR_STAMP(gi, s, 2);                                  // barrier passed
             const bool refill = it_issue < total;                // refills the slot every wave finished one stage ago
-            if (!ILV && refill) issue();
-            TR_STAMP(gi, s, 3);                                  // refill issued (ILV: it goes out row by row below)
+            if (refill) issue();
+            TR_STAMP(gi, s, 3);                                  // refill issued 
             const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
             if (s < NSTG / 2) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int l = s * R + r;
-                    if (ILV && refill) issue_row(r);
                     h16x8 kk = l2d_ld8(st + r * NT * 8);         // masked slots hold zeros
                     if (l == u) l2d_st8(ku + coff, kk);          // cache keeps the pre-PE projections (:117-119)
                     kk = kk + l2d_ld8(kpt + l * 320);            // fp16 rounding of K+pe as in the reference (:140)
                     sc[l] = ring_dot8(q8, kk);
                 }
-                if (ILV && refill) issue_done();
                 if (s == NSTG / 2 - 1) {
                     // per-head score reduction over the HG threads of a head, then the 1 x L softmax
 #pragma unroll
@@ -252,13 +248,11 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int l = (s - NSTG / 2) * R + r;
-                    if (ILV && refill) issue_row(r);
                     h16x8 vv = l2d_ld8(st + r * NT * 8);
                     if (l == u) l2d_st8(ku + slab + coff, vv);
                     vv = vv + l2d_ld8(vpt + l * 320);            // (:141)
                     ring_axpy8(o, sc[l], vv);
                 }
-                if (ILV && refill) issue_done();
             }
             TR_STAMP(gi, s, 4);                                  // stage arithmetic issued
             ++it;
@@ -271,213 +265,28 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
     }
 }
 
-// Loader-wave form.  In the kernel above every wave issues its share of a stage's refill (4 `global_load_lds`, ~200 cycles of
-// issue EACH in this kernel) and then does the stage's arithmetic: a stage is the sum of both, and neither interleaving the
-// two (measured: 2.7 % slower) nor more waves changes that, because issuing a DMA blocks the issuing wave.  Here a SIXTH wave
-// does nothing but issue: it owns the DMA descriptors of all 320 work items (5 wave-instructions per cache row), waits for its
-// own loads with the counted vmcnt and meets the five consumer waves at the stage barrier; the consumers run the arithmetic
-// of the kernel above and never touch the ring's VMEM queue.  Same LDS image, same stage order, same results bit for bit.
-template <int HG, int L, int R, int NS, int NLW>
-__global__ __launch_bounds__(320 + 64 * NLW) void tattn_stream_ringlw_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
-    // NLW loader waves: loader w issues the cache rows j = w (mod NLW) of every stage
-    constexpr int PB = 8, TP = 40, NT = TP * PB, NSTG = 2 * L / R, LPSL = 5 * R / NLW;
-    static_assert(R % NLW == 0, "rows of a stage must split evenly over the loader waves");
-    constexpr int STAGE_H = R * PB * TP * 8;
-    constexpr int LP = L + 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
-    h16 *ring = reinterpret_cast<h16 *>(ring_raw);
-    float *sp = reinterpret_cast<float *>(ring_raw + (size_t)NS * STAGE_H * sizeof(h16));
-    float *blds = sp + NT * LP;
-    h16 *kpl = reinterpret_cast<h16 *>(blds + L);
-    h16 *vpl = kpl + L * 320;
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 5;
-    const int lw = wave - 5;
-    const int C = a.C, CH = C / 320;
-    const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x / bpu);
-    const int n = __builtin_amdgcn_readfirstlane(unit / CH);
-    const int chunk = unit - n * CH;
-    const int g0 = (blockIdx.x - unit * bpu) * gpb;
-    const int ng = min(gpb, groups_per_unit - g0);
-    const long long slab = (long long)a.T * L * C;
-    h16 *kbase = a.cache + (long long)n * 2 * slab + (long long)g0 * PB * L * C + chunk * 320;
-    h16 *vbase = kbase + slab;
-    const h16 *qkv_b = a.qkv + ((long long)n * a.T + g0 * PB) * 3 * C + chunk * 320;
-    h16 *out_b = a.out + ((long long)n * a.T + g0 * PB) * C + chunk * 320;
-    const int u = __builtin_amdgcn_readfirstlane((int)a.update_idx[n]);
-    const long long *pei = a.pe_idx + (long long)n * L;
-    const h16 *bi = a.bias + (long long)n * L;
-    const int total = ng * NSTG;
-
-    if (loader) {
-        // ---------------------------------------------------------------- the loader wave
-        const int lane = tid & 63;
-        unsigned long long live = 0;
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-            if ((float)bi[l] > -1e30f && l != u) live |= 1ull << l;
-        live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(live >> 32)) << 32) |
-               (unsigned)__builtin_amdgcn_readfirstlane((int)(live & 0xffffffffull));
-        unsigned coff[5], qoff[5];                           // work item v = k * 64 + lane: pixel v / 40, channel slot v % 40
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int v = k * 64 + lane, p = v / TP, cc = v - p * TP;
-            coff[k] = (unsigned)(p * L * C + cc * 8);
-            qoff[k] = (unsigned)(p * 3 * C + cc * 8);
-        }
-        int it_issue = 0, is_s = 0, is_slot = 0, is_g = 0;
-        auto issue = [&]() {
-            const bool isv = is_s >= NSTG / 2;
-            const int l0 = (isv ? is_s - NSTG / 2 : is_s) * R;
-            const h16 *cb = (isv ? vbase : kbase) + (long long)is_g * (PB * L * C);
-            const h16 *qb = qkv_b + (long long)is_g * (PB * 3 * C) + (isv ? 2 * C : C);
-            h16 *dst = ring + is_slot * STAGE_H;
-#pragma unroll
-            for (int jj = 0; jj < R / NLW; ++jj) {
-                const int j = jj * NLW + lw;                 // uniform
-                const int l = l0 + j;
-                const unsigned long long lv = 0ull - ((live >> l) & 1ull);
-                const unsigned long long nw = (0ull - (unsigned long long)(l == u ? 1u : 0u)) & ~lv;
-                const unsigned long long sb = ((unsigned long long)(cb + l * C) & lv) | ((unsigned long long)qb & nw) |
-                                              ((unsigned long long)zero & ~(lv | nw));
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const unsigned vo = (coff[k] & (unsigned)lv) | (qoff[k] & (unsigned)nw);
-                    __builtin_amdgcn_global_load_lds(L2D_GPTR(reinterpret_cast<const h16 *>(sb) + vo), L2D_LPTR(dst + j * NT * 8 + k * 512), 16, 0, 0);
-                }
-            }
-            ++it_issue;
-            if (++is_s == NSTG) { is_s = 0; ++is_g; }
-            is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
-        };
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (it_issue < total) issue();
-        int it = 0;
-        for (int gi = 0; gi < ng; ++gi) {
-#pragma unroll 1
-            for (int s = 0; s < NSTG; ++s) {
-                if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPSL) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                // stage `it` is in LDS; the consumers finished stage it - 1
-                if (it_issue < total) issue();
-                if (s == NSTG / 2 - 1) __builtin_amdgcn_s_barrier();      // the consumers' score exchange barrier
-                ++it;
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- the five consumer waves (arithmetic of the kernel above)
-    const int p = tid / TP, cc = tid - p * TP;
-    const unsigned coff = (unsigned)(p * L * C + cc * 8);
-    const unsigned qoff = (unsigned)(p * 3 * C + cc * 8);
-    const unsigned ooff = (unsigned)(p * C + cc * 8);
-    if (tid < L) blds[tid] = (float)bi[tid];
-#pragma unroll
-    for (int f0 = 0; f0 < L * TP; f0 += NT) {
-        const int f = f0 + tid;
-        if (f < L * TP) {
-            const int l = f / TP, c = f - l * TP;
-            const long long po = pei[l] * C + chunk * 320 + c * 8;
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.k_pe + po), L2D_LPTR(kpl + (f0 + wave * 64) * 8), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(L2D_GPTR(a.v_pe + po), L2D_LPTR(vpl + (f0 + wave * 64) * 8), 16, 0, 0);
-        }
-    }
-    const h16x8 qpe = l2d_ld8(a.q_pe + pei[u] * C + chunk * 320 + cc * 8);
-    h16x8 qn = l2d_ld8(qkv_b + qoff);
-    // the PE rows were DMA'd by THIS wave: they must have landed before the first stage barrier publishes them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    const float scale = rsqrtf((float)(C / a.H));
-    const int gs = p * TP + (cc / HG) * HG;
-    float *row = sp + tid * LP;
-    const h16 *kpt = kpl + cc * 8, *vpt = vpl + cc * 8;
-    int cs_slot = 0;
-    for (int gi = 0; gi < ng; ++gi) {
-        h16x8 q8 = qn + qpe;                                 // fp16 add, as the reference (:139)
-        h16 *ku = kbase + (long long)gi * (PB * L * C) + u * C;
-        float sc[L];
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < NSTG; ++s) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the previous stage are done
-            __builtin_amdgcn_s_barrier();
-            const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
-            if (s < NSTG / 2) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int l = s * R + r;
-                    h16x8 kk = l2d_ld8(st + r * NT * 8);
-                    if (l == u) l2d_st8(ku + coff, kk);
-                    kk = kk + l2d_ld8(kpt + l * 320);
-                    sc[l] = ring_dot8(q8, kk);
-                }
-                if (s == NSTG / 2 - 1) {
-#pragma unroll
-                    for (int l = 0; l < L; l += 4) *reinterpret_cast<f32x4 *>(row + l) = (f32x4){sc[l], sc[l + 1], sc[l + 2], sc[l + 3]};
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-#pragma unroll
-                    for (int l = 0; l < L; ++l) sc[l] = 0.f;
-#pragma unroll 2
-                    for (int j = 0; j < HG; ++j) {
-                        const float *rr = sp + (gs + j) * LP;
-#pragma unroll
-                        for (int l = 0; l < L; l += 4) {
-                            f32x4 x = *reinterpret_cast<const f32x4 *>(rr + l);
-                            sc[l] += x[0]; sc[l + 1] += x[1]; sc[l + 2] += x[2]; sc[l + 3] += x[3];
-                        }
-                    }
-                    float mx = -3.0e38f;
-#pragma unroll
-                    for (int l = 0; l < L; l += 4) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(blds + l);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { sc[l + e] = sc[l + e] * scale + b4[e]; mx = fmaxf(mx, sc[l + e]); }
-                    }
-                    float den = 0.f;
-#pragma unroll
-                    for (int l = 0; l < L; ++l) { sc[l] = __expf(sc[l] - mx); den += sc[l]; }
-                    const float inv = 1.0f / den;
-#pragma unroll
-                    for (int l = 0; l < L; ++l) sc[l] *= inv;
-                }
-            } else {
-                if (s == NSTG / 2 && gi + 1 < ng)
-                    qn = l2d_ld8(qkv_b + (long long)(gi + 1) * (PB * 3 * C) + qoff);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int l = (s - NSTG / 2) * R + r;
-                    h16x8 vv = l2d_ld8(st + r * NT * 8);
-                    if (l == u) l2d_st8(ku + slab + coff, vv);
-                    vv = vv + l2d_ld8(vpt + l * 320);
-                    ring_axpy8(o, sc[l], vv);
-                }
-            }
-            cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
-        }
-        h16x8 ov;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = (h16)o[e];
-        l2d_st8(out_b + (long long)gi * (PB * C) + ooff, ov);
-    }
-}
-
-// Long windows (L = 40: cfg-5, 17 GB of cache per frame).  The kernels above keep a row's L scores in registers across a
-// fully unrolled stage loop (2 L / R stages): at L = 40 that loop is 40 stages long, hipcc stops unrolling it and the score
-// array lands in scratch (176 bytes per lane; measured 2.0 TB/s, below the old chunked kernel).  Here the stage loops are
-// ordinary loops: the partial scores of a row go straight into the thread's LDS score row, the L-wide softmax runs once on
-// registers between the K and the V stages, and the probabilities are written back to the thread's own score row, from where
-// the V stages read them -- two block barriers per pixel group instead of one, everything else (loader wave, ring, DMA
-// images, rounding points) as above.  The gathered PE rows and the score rows leave 50 KB for the ring: 5 stages of 2 rows.
+// Loader-wave form (round 3, the default).  In the kernel above every wave issues its share of a stage's refill (4
+// `global_load_lds`, ~200 cycles of issue EACH in this kernel) and then does the stage's arithmetic: a stage is the sum of
+// both, and neither interleaving the two (measured: 2.7 % slower) nor more waves changes that, because issuing a DMA blocks the
+// issuing wave.  Here a SIXTH wave does nothing but issue: it owns the DMA descriptors of all 320 work items (5
+// wave-instructions per cache row), waits for its own loads with the counted vmcnt and meets the five consumer waves at the
+// stage barrier; the consumers run the arithmetic and never touch the ring's VMEM queue.  Same LDS image, same stage order,
+// same rounding points, same results bit for bit.  cfg-2 frame: 1.02 -> 0.89 ms (profiles/r3f_tattn_loader_wave_ab.txt); two
+// and four loader waves measured the same as one (r3g): the loader is not what bounds a stage any more.
+//
+// Scores in LDS.  The first loader-wave kernel kept a row's L scores in registers across a fully unrolled stage loop (2 L / R
+// stages).  At L = 40 that loop is 40 stages long, hipcc stops unrolling it and the score array lands in scratch (176 bytes
+// per lane; 2.0 TB/s, no better than the chunked kernel of tattn.hip).  Here the stage loops are ordinary loops: the partial
+// scores of a row go straight into the thread's LDS score row, the L-wide softmax runs once on registers between the K and
+// the V stages, and the probabilities are written back to the thread's own score row, from where the V stages read them --
+// two block barriers per pixel group for the exchange instead of one, 110 VGPRs instead of 154-221, no unrolled code.
+// Measured against the unrolled form with the same ring geometry (profiles/r3j_tattn_lds_scores_ab.txt): L = 16 0.895 ->
+// 0.876 ms per cfg-2 frame, L = 24 (cfg-3) 1.89 -> 1.76 ms, and L = 40 (cfg-5, 17 GB of cache per frame) 8.82 -> 3.99 ms
+// against the chunked kernel (0.25 -> 0.56 of 8 TB/s, profiles/r3i_tattn_l40_ring_vs_chunked.txt) -- so this is the one form
+// for every window.  Ring geometry: (4 rows, 5 stages) = 100 KB for L <= 16, (4, 4) for L = 24, (2, 5) for L = 40, where the
+// gathered PE rows (2 x 25 KB) and the score rows (55 KB) leave 50 KB for the ring.
 template <int HG, int L, int R, int NS>
-__global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
+__global__ __launch_bounds__(384) void tattn_stream_ringlw_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
     constexpr int PB = 8, TP = 40, NT = TP * PB, NSTG = 2 * L / R, LPSL = 5 * R;
     constexpr int STAGE_H = R * PB * TP * 8;
     constexpr int LP = L + 4;
@@ -554,10 +363,15 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
         for (int gi = 0; gi < ng; ++gi) {
 #pragma unroll 1
             for (int s = 0; s < NSTG; ++s) {
+                TR_STAMP(gi, s, 0);                          // loader: stage top
                 if (total - 1 - it >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPSL) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TR_STAMP(gi, s, 1);                          // stage `it` has landed
                 __builtin_amdgcn_s_barrier();
+                TR_STAMP(gi, s, 2);                          // barrier passed (the consumers finished stage it - 1)
                 if (it_issue < total) issue();
+                TR_STAMP(gi, s, 3);                          // refill issued
+                TR_STAMP(gi, s, 4);
                 if (s == NSTG / 2 - 1) {                     // the consumers' two softmax barriers
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_s_barrier();
@@ -598,8 +412,12 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
         // ---- K stages: partial scores of this thread's 8 channels -> its LDS score row
 #pragma unroll 1
         for (int s = 0; s < NSTG / 2; ++s) {
+            TR_STAMP(gi, s, 0);                              // consumer: stage top
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TR_STAMP(gi, s, 1);                              // own LDS reads of the previous stage done
             __builtin_amdgcn_s_barrier();
+            TR_STAMP(gi, s, 2);                              // barrier passed: the stage is in LDS
+            TR_STAMP(gi, s, 3);
             const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
             float d[R];
 #pragma unroll
@@ -615,6 +433,7 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
 #pragma unroll
                 for (int r = 0; r < R; ++r) row[s * R + r] = d[r];
             }
+            TR_STAMP(gi, s, 4);                              // stage arithmetic issued
             cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
         }
         // ---- per-head reduction over the HG threads of a head + the 1 x L softmax, on registers
@@ -654,8 +473,12 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
 #pragma unroll 1
         for (int s = 0; s < NSTG / 2; ++s) {
+            TR_STAMP(gi, s + NSTG / 2, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TR_STAMP(gi, s + NSTG / 2, 1);
             __builtin_amdgcn_s_barrier();
+            TR_STAMP(gi, s + NSTG / 2, 2);
+            TR_STAMP(gi, s + NSTG / 2, 3);
             const h16 *st = ring + cs_slot * STAGE_H + tid * 8;
             float pr[R];
             if constexpr (R == 2) { const f32x2 t = *reinterpret_cast<const f32x2 *>(row + s * 2); pr[0] = t[0]; pr[1] = t[1]; }
@@ -671,6 +494,7 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
                 vv = vv + l2d_ld8(vpt + l * 320);
                 ring_axpy8(o, pr[r], vv);
             }
+            TR_STAMP(gi, s + NSTG / 2, 4);
             cs_slot = (cs_slot + 1 == NS) ? 0 : cs_slot + 1;
         }
         h16x8 ov;
@@ -681,33 +505,13 @@ __global__ __launch_bounds__(384) void tattn_stream_ringlw_long_kernel(TAttnArgs
 }
 
 template <int L, int HG, int R, int NS>
-static void launch_ringlw_long(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
-    constexpr int NT = 320;
-    constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
-    static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)tattn_stream_ringlw_long_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
-            attr_done = true;
-        else
-            (void)hipGetLastError();
-    }
-    const int CH = a.C / 320;
-    const int groups_per_unit = a.T / 8;
-    const int total = a.N * CH * groups_per_unit;
-    const int gpb = (total + slots - 1) / slots;
-    const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    hipLaunchKernelGGL((tattn_stream_ringlw_long_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(384), LDS, s, a, zero, gpb, groups_per_unit);
-}
-
-template <int L, int HG, int R, int NS, int NLW = 1>
 static void launch_ringlw(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
     constexpr int NT = 320;
     constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)tattn_stream_ringlw_kernel<HG, L, R, NS, NLW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)tattn_stream_ringlw_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
@@ -717,18 +521,17 @@ static void launch_ringlw(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     const int total = a.N * CH * groups_per_unit;
     const int gpb = (total + slots - 1) / slots;
     const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    hipLaunchKernelGGL((tattn_stream_ringlw_kernel<HG, L, R, NS, NLW>), dim3(a.N * CH * bpu), dim3(320 + 64 * NLW), LDS, s, a, zero, gpb, groups_per_unit);
+    hipLaunchKernelGGL((tattn_stream_ringlw_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(384), LDS, s, a, zero, gpb, groups_per_unit);
 }
 
-template <int L, int HG, int R, int NS, int PB, bool ILV = false>
+template <int L, int HG, int R, int NS, int PB>
 static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
     constexpr int NT = 40 * PB;
     constexpr size_t LDS = (size_t)NS * R * PB * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
     static bool attr_done = false;
-    if (!attr_done) {    // > 64 KB of dynamic LDS must be opted into once per kernel (not inside a stream capture: the
-        // plan's first run is always direct; on failure the flag stays clear and the launch below reports the error)
-        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS, PB, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
@@ -736,44 +539,28 @@ static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     const int CH = a.C / 320;
     const int groups_per_unit = a.T / PB;
     const int total = a.N * CH * groups_per_unit;
-    const int gpb = (total + slots - 1) / slots;   // LDS-filling blocks, persistent over gpb pixel groups
+    const int gpb = (total + slots - 1) / slots;
     const int bpu = (groups_per_unit + gpb - 1) / gpb;
-    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS, PB, ILV>), dim3(a.N * CH * bpu), dim3(NT), LDS, s, a, zero, gpb, groups_per_unit);
+    hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS, PB>), dim3(a.N * CH * bpu), dim3(NT), LDS, s, a, zero, gpb, groups_per_unit);
 }
 
 template <int L, int HG>
 static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
-    // tuning knob L2D_TATTN_RING: -1 auto; 0 = 8 pixels, (4 rows, 5 stages), 1 block / CU; 1 = 8 pixels, (2, 3), 2 blocks / CU;
-    // 2 = 16 pixels (10 waves), (2 rows, 4 stages), 1 block / CU; 3 = 8 pixels (4, 5) with the refill DMAs interleaved with the
-    // row arithmetic (measured 2.7 % SLOWER than back to back: profiles/r3e_tattn_interleave_ab.txt); 4 = round-2 form (every wave
-    // issues its own DMAs); default = ONE dedicated loader wave (1.02 -> 0.89 ms per cfg-2 frame; 5 / 6 = two / four loader
-    // waves: no faster, profiles/r3g_tattn_loader_waves_ab.txt)
+    // L2D_TATTN_RING=4: the round-2 form (every wave issues its own DMAs; L <= 24), for A/B; default: the loader-wave kernel
     static int geo = -2;
     if (geo == -2) {
         const char *e = getenv("L2D_TATTN_RING");
         geo = e ? atoi(e) : -1;
     }
-    int g = geo;
-    const long long groups16 = (long long)a.N * (a.C / 320) * (a.T / 16);
-    if (g == -1) g = 0;
-    (void)groups16;
-    if (g == 2 && a.T % 16 != 0) g = 0;
     if constexpr (L <= 16) {
-        if (g == 1) launch_ring_g<L, HG, 2, 3, 8>(a, zero, 2 * cus, s);
-        else if (g == 2) launch_ring_g<L, HG, 2, 4, 16>(a, zero, cus, s);
-        else if (g == 3) launch_ring_g<L, HG, 4, 5, 8, true>(a, zero, cus, s);       // A/B: refill DMAs interleaved with the row arithmetic
-        else if (g == 4) launch_ring_g<L, HG, 4, 5, 8, false>(a, zero, cus, s);      // round-2 form: every wave issues its own DMAs
-        else if (g == 5) launch_ringlw<L, HG, 4, 5, 2>(a, zero, cus, s);             // two loader waves (same time as one: the loader
-        else if (g == 6) launch_ringlw<L, HG, 4, 5, 4>(a, zero, cus, s);             //  is no longer what bounds the stage)
-        else launch_ringlw<L, HG, 4, 5, 1>(a, zero, cus, s);                          // one loader wave + 5 consumer waves
+        if (geo == 4) launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s);
+        else launch_ringlw<L, HG, 4, 5>(a, zero, cus, s);
     } else if constexpr (L == 24) {
-        // longer windows: the score rows ([320][L + 4] f32) and the gathered PE rows (2 x L x 640 B) grow with L, the ring
-        // gets what is left of the 160 KB: 4 stages x 4 rows (80 KB) at L = 24, 5 stages x 2 rows (50 KB) at L = 40
-        if (g == 4) launch_ring_g<L, HG, 4, 4, 8>(a, zero, cus, s);
-        else if (g == 5) launch_ringlw<L, HG, 4, 4, 2>(a, zero, cus, s);
-        else launch_ringlw<L, HG, 4, 4, 1>(a, zero, cus, s);
+        // 24 slots: PE rows 2 x 15 KB + score rows 35 KB leave room for 4 stages of 4 rows ((2 rows, 8 stages): 3 % slower)
+        if (geo == 4) launch_ring_g<L, HG, 4, 4, 8>(a, zero, cus, s);
+        else launch_ringlw<L, HG, 4, 4>(a, zero, cus, s);
     } else {
-        launch_ringlw_long<L, HG, 2, 5>(a, zero, cus, s);
+        launch_ringlw<L, HG, 2, 5>(a, zero, cus, s);
     }
 }
 

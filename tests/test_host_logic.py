@@ -296,8 +296,9 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     n, fl, by = tot[_lib.OP_TATTN_STREAM]
     assert n == 40 and abs(by - (kv_bytes + 2 * kv_bytes / cfg.window_size)) < 1e-6 * by   # K+V once + (row write, q, out) = 8 N T C bytes
     # 380 GEMM launches in round 2; the 16 V^T projections now ride in the q | k | V^T row GEMMs
-    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and tot[_lib.OP_IGEMM][0] + tot[_lib.OP_ROWGEMM][0] == 380 - 16
-    assert abs((tot[_lib.OP_IGEMM][1] + tot[_lib.OP_ROWGEMM][1]) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
+    gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV)]      # (21 level-0 / level-1 3x3 convs: patch kernel)
+    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 and tot[_lib.OP_PCONV][0] == 21
+    assert abs(sum(g_[1] for g_ in gemm) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
     assert _lib.OP_LAYERNORM not in tot
 
 

@@ -70,15 +70,15 @@ def test_occupancy_budgets(kernels):
     for n, k in pick(r"flash_ring_kernelILi(40|80)ELi1ELi4ELi0E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
     # KV-cache ring kernel: 5 waves per block, one block per CU (10 waves with the 16-pixel geometry: three on two SIMDs)
-    # (L = 24: one block of 5 / 6 waves per CU = at most two waves per SIMD, so up to 256 registers cost nothing)
-    for n, k in pick(r"tattn_stream_ring(lw)?_kernelILi\d+ELi(12|16)E").items():
+    # round-2 ring form (A/B only; L = 24: one block of 5 waves per CU = at most two waves per SIMD, so up to 256 registers cost nothing)
+    for n, k in pick(r"tattn_stream_ring_kernelILi\d+ELi(12|16)E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
-    for n, k in pick(r"tattn_stream_ring(lw)?_kernelILi\d+ELi24E").items():
+    for n, k in pick(r"tattn_stream_ring_kernelILi\d+ELi24E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 256, (n, k)
-    # long-window loader-wave form (L = 40): no scratch -- the fully unrolled form's score array went to scratch there, and a
-    # scratch load would also break the loader's counted vmcnt
-    lw = pick(r"tattn_stream_ringlw_long_kernel")
-    assert len(lw) == 3, sorted(lw)
+    # loader-wave kernel (the default for every window, scores in LDS): no scratch -- the unrolled form's score array went to
+    # scratch at L = 40, and a scratch load would also break the loader's counted vmcnt -- and <= 128 registers
+    lw = pick(r"tattn_stream_ringlw_kernel")
+    assert len(lw) == 12, sorted(lw)                       # L in {12, 16, 24, 40} x head widths {5, 10, 20} threads
     for n, k in lw.items():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_count"] + k["agpr_count"] <= 128, (n, k)
     # token-resident GEMM, compile-time K: the geometries with up to 8 waves per block rely on <= 256 registers, no spills

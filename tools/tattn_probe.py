@@ -34,12 +34,21 @@ for (C, T) in ((320, 4096), (640, 1024)):
     pl.run()
     torch.cuda.synchronize()
     _lib.lib.l2d_tattn_set_probe(None)
-    p = probe.view(-1, 2, 8).cpu()
+    p = probe.view(-1, 16, 2, 8).cpu()
     gb = N * 2 * T * L * C * 2 / (us * 1e-6) / 1e9
     print(f"C{C} T{T}: {us:.1f} us = {gb:.0f} GB/s of cache")
-    for kind, name in ((0, "K stage"), (1, "V stage")):
-        q = p[:, kind, :5]
-        q = q[(q > 0).all(1)].double()
-        d = q[:, 1:] - q[:, :-1]
-        med, p90 = d.median(0).values, d.quantile(0.9, dim=0)
-        print(f"   {name}: {q.shape[0]} waves; " + "  ".join(f"{n} {int(m)} (p90 {int(h)})" for n, m, h in zip(["wait DMA", "barrier", "issue refill", "arithmetic"], med, p90)))
+    loader_wave = 5 if os.environ.get("L2D_TATTN_RING", "") != "4" else None     # the loader-wave kernel: wave 5 only issues DMAs
+    for who, sel in (("consumer waves", [w for w in range(5)]), ("loader wave", [5] if loader_wave else [])):
+        if not sel:
+            continue
+        for kind, name in ((0, "K stage"), (1, "V stage")):
+            q = p[:, sel, kind, :5].reshape(-1, 5)
+            q = q[(q > 0).all(1)].double()
+            if not q.shape[0]:
+                continue
+            d = q[:, 1:] - q[:, :-1]
+            med, p90 = d.median(0).values, d.quantile(0.9, dim=0)
+            names = ["wait own LDS reads", "barrier", "-", "arithmetic"] if (loader_wave and who[0] == "c") else \
+                    ["wait DMA landed", "barrier", "issue refill", "-"] if who[0] == "l" else ["wait DMA", "barrier", "issue refill", "arithmetic"]
+            print(f"   {who}, {name}: {q.shape[0]} waves; " + "  ".join(f"{n} {int(m)} (p90 {int(h)})" for n, m, h in zip(names, med, p90))
+                  + f"  | stage total {int((q[:, 4] - q[:, 0]).median())}")
