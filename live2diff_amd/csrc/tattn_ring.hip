@@ -73,7 +73,7 @@ __device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
 // in-kernel stage stamps (tools/tattn_probe.py): every one of the five waves issues its own share of a stage's refill and then
 // does the stage's arithmetic.  HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) =
 // 100 KB of ring, one block of PB = 8 pixels x 40 threads per CU.  Geometries that were measured and removed again (round 2 /
-// round 3, profiles/r2l*, r3e_*): (2 rows, 3 stages) with two blocks per CU (10 % slower), 16-pixel / 10-wave blocks (equal),
+// round 3, profiles/r2l*, round3_e_*): (2 rows, 3 stages) with two blocks per CU (10 % slower), 16-pixel / 10-wave blocks (equal),
 // refill DMAs interleaved row by row with the arithmetic (2.7 % slower).
 template <int HG, int L, int R, int NS, int PB>
 __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a, const h16 *zero, int gpb, int groups_per_unit) {
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
 // issuing wave.  Here a SIXTH wave does nothing but issue: it owns the DMA descriptors of all 320 work items (5
 // wave-instructions per cache row), waits for its own loads with the counted vmcnt and meets the five consumer waves at the
 // stage barrier; the consumers run the arithmetic and never touch the ring's VMEM queue.  Same LDS image, same stage order,
-// same rounding points, same results bit for bit.  cfg-2 frame: 1.02 -> 0.89 ms (profiles/r3f_tattn_loader_wave_ab.txt); two
-// and four loader waves measured the same as one (r3g): the loader is not what bounds a stage any more.
+// same rounding points, same results bit for bit.  cfg-2 frame: 1.02 -> 0.89 ms (profiles/round3_f_tattn_loader_wave_ab.txt); two
+// and four loader waves measured the same as one (round3_g): the loader is not what bounds a stage any more.
 //
 // Scores in LDS.  The first loader-wave kernel kept a row's L scores in registers across a fully unrolled stage loop (2 L / R
 // stages).  At L = 40 that loop is 40 stages long, hipcc stops unrolling it and the score array lands in scratch (176 bytes
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
 // scores of a row go straight into the thread's LDS score row, the L-wide softmax runs once on registers between the K and
 // the V stages, and the probabilities are written back to the thread's own score row, from where the V stages read them --
 // two block barriers per pixel group for the exchange instead of one, 110 VGPRs instead of 154-221, no unrolled code.
-// Measured against the unrolled form with the same ring geometry (profiles/r3j_tattn_lds_scores_ab.txt): L = 16 0.895 ->
+// Measured against the unrolled form with the same ring geometry (profiles/round3_j_tattn_lds_scores_ab.txt): L = 16 0.895 ->
 // 0.876 ms per cfg-2 frame, L = 24 (cfg-3) 1.89 -> 1.76 ms, and L = 40 (cfg-5, 17 GB of cache per frame) 8.82 -> 3.99 ms
-// against the chunked kernel (0.25 -> 0.56 of 8 TB/s, profiles/r3i_tattn_l40_ring_vs_chunked.txt) -- so this is the one form
+// against the chunked kernel (0.25 -> 0.56 of 8 TB/s, profiles/round3_i_tattn_l40_ring_vs_chunked.txt) -- so this is the one form
 // for every window.  Ring geometry: (4 rows, 5 stages) = 100 KB for L <= 16, (4, 4) for L = 24, (2, 5) for L = 40, where the
 // gathered PE rows (2 x 25 KB) and the score rows (55 KB) leave 50 KB for the ring.
 template <int HG, int L, int R, int NS>

@@ -165,7 +165,7 @@ class HipStreamingUNet:
             with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
             # Row GEMM where it fuses a norm, and for the narrow levels (K <= 640).  A plain Linear at K = 1280 stays on the
             # implicit-GEMM kernel: with 32-token row tiles every block ingests its whole weight band (80 KB per 32-row tile), and
-            # the probe (profiles/r3b_rowgemm_block_phases.txt) shows those launches bound by ~30 B/clk of ingest per CU.
+            # the probe (profiles/round3_b_rowgemm_block_phases_before.txt) shows those launches bound by ~30 B/clk of ingest per CU.
             rg = rg_ok(name + ".weight") and (norm is not None or sd[name + ".weight"][0].numel() <= RG_PLAIN_MAX_K)
             if rg:
                 W[name + ".rw"], rb = ops.pack_rowgemm(g(name + ".weight"), g(name + ".bias") if bias else None,
