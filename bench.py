@@ -513,7 +513,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = (json.load(open(tpath)).get(name) or {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))      # (the ring build of the flash op is traced under its own kernel name)
+            traffic = (tj.get(name) or tj.get({"flash_attn_kernel": "flash_ring_kernel"}.get(name, name)) or {}).get("hbm_bytes_per_launch")
         tsrc = ("static: profiles/traffic.json = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
                 "not collected inside this run") if traffic is not None else None
         if name in MFMA_KERNELS:

@@ -154,6 +154,7 @@ class HipStreamingUNet:
 
         use_rg = os.environ.get("L2D_ROWGEMM", "1") != "0"     # A/B knob: 0 = every linear layer on igemm + separate norm launches
         RG_PLAIN_MAX_K = int(os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"))
+        RG_FF1_MAX_K = int(os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))     # A/B knob: GEGLU GEMMs wider than this stay on igemm
 
         def rg_ok(wname):
             n, k = sd[wname].shape[0], sd[wname][0].numel()
@@ -183,7 +184,7 @@ class HipStreamingUNet:
 
         def ff(name, norm, old=False):
             pw, pb = name + ".net.0.proj.weight", name + ".net.0.proj.bias"
-            rg = rg_ok(pw) and sd[pw].shape[0] % 64 == 0
+            rg = rg_ok(pw) and sd[pw].shape[0] % 64 == 0 and sd[pw][0].numel() <= RG_FF1_MAX_K
             if rg:
                 W[name + ".rw1"], W[name + ".rb1"] = ops.pack_rowgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"), geglu=True)
             if not rg or old:

@@ -40,6 +40,7 @@ def main():
     wp = ops.pack_conv3x3(rn(cout, cin, 3, 3) * (9 * cin) ** -0.5)
     out = torch.empty(B * H * W, cout, dtype=torch.float16, device=DEV)
     bias = torch.zeros(cout, device=DEV)
+    xres = rn(B * H * W, cout)
     for tile in (2, 1):
         for _ in range(REPS):
             run(ops.igemm(x, wp, out, M=B * H * W, Nout=cout, C1=cin, ldx1=cin, CinP=wp.shape[1] // 9, ldo=cout, bias=bias, taps=9,
@@ -49,6 +50,26 @@ def main():
     o1 = torch.empty(8192, 1280, dtype=torch.float16, device=DEV)
     for _ in range(REPS):
         run(ops.igemm(x, w1, o1, M=8192, Nout=2560, C1=320, ldx1=320, CinP=320, ldo=1280, bias=b1, epi=1, tile=1), VARIANT)
+    # --- patch-resident 3x3 conv (pconv.hip): level-0 320 -> 320 and the concat conv 640 -> 320, 8x16 patches
+    for cin_ in (320, 640):
+        xx = rn(B * H * W, cin_)
+        wq = ops.pack_conv3x3(rn(cout, cin_, 3, 3) * (9 * cin_) ** -0.5)
+        for _ in range(REPS):
+            run(ops.pconv(xx, wq, out, B=B, H=H, W=W, C1=cin_, ldx1=cin_, CinP=cin_, Nout=cout, ldo=cout, patch=(8, 16), bias=bias))
+    # --- token-row GEMM (rowgemm.hip), level 0: LayerNorm + GEGLU (M8192 N2560 K320), LayerNorm + q|k|V^T (N960), plain C x C
+    gam, bet = torch.ones(320, device=DEV), torch.zeros(320, device=DEV)
+    rw1, rb1 = ops.pack_rowgemm(rn(2560, 320) * 320 ** -0.5, torch.zeros(2560, device=DEV), gam, bet, geglu=True)
+    for _ in range(REPS):
+        run(ops.rowgemm(x, rw1, o1, M=8192, K=320, Nout=2560, ldx=320, ldo=1280, bias=rb1, epi=1, pro=1))
+    rwq, rbq = ops.pack_rowgemm(rn(960, 320) * 320 ** -0.5, None, gam, bet)
+    oqk = torch.empty(8192, 640, dtype=torch.float16, device=DEV)
+    ovt = torch.empty(2, 320, 4096, dtype=torch.float16, device=DEV)
+    for _ in range(REPS):
+        run(ops.rowgemm(x, rwq, oqk, M=8192, K=320, Nout=960, ldx=320, ldo=640, bias=rbq, pro=1, T=4096, out_t=ovt, ntr=320, ldt=4096,
+                        st=320 * 4096))
+    rwc, rbc = ops.pack_rowgemm(rn(320, 320) * 320 ** -0.5, torch.zeros(320, device=DEV))
+    for _ in range(REPS):
+        run(ops.rowgemm(x, rwc, out, M=8192, K=320, Nout=320, ldx=320, ldo=320, bias=rbc, res=xres, ldr=320))
     # --- streaming temporal attention, level 0: N=2, T=4096, C=320, L=16; a fresh 168 MB cache per repetition
     N, T, C, L = 2, 4096, 320, 16
     qkv = rn(N * T, 3 * C)
