@@ -125,8 +125,10 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
     const int RPP = nthr / CPR;
     const int rr = tid / CPR, cc = tid - rr * CPR;
     const bool on = rr < RPP;
-    h16x8 resv[EIT];
-    if (a.res && y < a.ytr) {
+    // (128-token tiles keep 64-128 accumulator registers: their residual rows are fetched in the epilogue instead)
+    constexpr bool RES_PRE = MT <= 2;
+    h16x8 resv[RES_PRE ? EIT : 1];
+    if (RES_PRE && a.res && y < a.ytr) {
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
             int row = rr + it * RPP;
@@ -276,7 +278,10 @@ __device__ __forceinline__ void rowgemm_body(const RowGemmArgs &a, h16 *smem, h1
         const int row = rr + it * RPP;
         if (!on || row >= BM || m0 + row >= a.M) continue;
         h16x8 v = l2d_ld8(os + row * pitch + cc * 8);
-        if (a.res) v = v + resv[it];
+        if (a.res) {
+            if constexpr (RES_PRE) v = v + resv[it];
+            else v = v + l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + cc * 8);
+        }
         l2d_st8(a.out + (long long)(m0 + row) * a.ldo + nb_o + cc * 8, v);
         if (gn) {
 #pragma unroll
@@ -563,8 +568,8 @@ int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s) {
     const int BM = 32 * MT;
     const int tiles = a.Nout > 0 ? a.Nout / 32 : 0;
     // (launch bounds of the instantiations below: NT <= 2 up to 8 waves, NT >= 3 up to 5)
-    const bool geom_ok = NW >= 1 && NW <= (NT >= 3 ? 5 : 8) && NT >= 1 && NT <= 4 && (MT == 1 || MT == 2) &&
-                         !(MT == 2 && NT > 2) &&
+    const bool geom_ok = NW >= 1 && NW <= (NT >= 3 ? 5 : 8) && NT >= 1 && NT <= 4 && (MT == 1 || MT == 2 || MT == 4) &&
+                         !(MT >= 2 && NT > 2) && !(MT == 4 && a.K != 320) &&   // (128-token tiles: K = 320 only -- 80 KB of LDS)
                          tiles > 0 && (a.Nout % 32) == 0 && (tiles % (NW * NT)) == 0 && ntr >= 0 && ntr <= tiles &&
                          (ntr % (NW * NT)) == 0;
     if (!a.x || !a.w || a.M <= 0 || a.K <= 0 || (a.K % 64) || a.K > 2048 || !geom_ok || (a.ldx % 8) || a.ldx < a.K ||
@@ -613,9 +618,12 @@ int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s) {
             case 3: launch_k<3, 1, 5, 320>(a, nthr, lds, s); break;
             default: launch_k<4, 1, 4, 320>(a, nthr, lds, s); break;
         }
-    } else {
+    } else if (MT == 2) {
         if (NT == 1) launch_k<1, 2, 16, 512>(a, nthr, lds, s);
         else launch_k<2, 2, 8, 512>(a, nthr, lds, s);
+    } else {
+        if (NT == 1) launch_rg<1, 4, 8, 20, 512>(a, nthr, lds, s);
+        else launch_rg<2, 4, 4, 20, 512>(a, nthr, lds, s);
     }
     return l2d_check_launch("rowgemm", op->tag);
 }

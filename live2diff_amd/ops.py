@@ -249,6 +249,16 @@ def _rowgemm_lds(K, NW, NT, MT, epi, pro, ntr, gn):
     return max(xs, os_)
 
 
+def _rowgemm_mt_ok(mt, nt, K, T):
+    """token tiles per block: 1, 2 (NT <= 2) or 4 (NT <= 2, K = 320: 80 KB of LDS); with T given (a norm prologue from group
+    statistics, a transposed output or output statistics) a sample must be a whole number of token tiles"""
+    if mt == 1:
+        return True
+    if mt not in (2, 4) or nt > 2 or (mt == 4 and K != 320):
+        return False
+    return T % (32 * mt) == 0
+
+
 def rowgemm_schedule(M: int, K: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0, gn: bool = True, T: int = 0):
     """(NW, NT, MT) = waves per block, 32-row weight tiles per wave, 32-token tiles per block for a rowgemm launch.  A table
     measured on MI355X (rowgemm_tuned.json, tools/rowgemm_sweep.py) when it holds the shape, else a small cost model:
@@ -259,11 +269,11 @@ def rowgemm_schedule(M: int, K: int, Nout: int, ntr: int = 0, epi: int = 0, pro:
     force = os.environ.get("L2D_ROWGEMM_FORCE")        # "NW,NT,MT" (tools): applied where it divides the shape
     if force:
         nw, nt, mt = (int(v) for v in force.split(","))
-        if tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0 and nw <= (5 if nt >= 3 else 8) and not (mt == 2 and (nt > 2 or T % 64)) \
+        if tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0 and nw <= (5 if nt >= 3 else 8) and _rowgemm_mt_ok(mt, nt, K, T) \
                 and _rowgemm_lds(K, nw, nt, mt, epi, pro, ntr, gn) <= 163840:
             return nw, nt, mt
     key = f"{M},{K},{Nout},{ntr},{epi}"
-    if key in _RG_TUNED and not (_RG_TUNED[key][2] == 2 and T % 64):
+    if key in _RG_TUNED and _rowgemm_mt_ok(_RG_TUNED[key][2], _RG_TUNED[key][1], K, T):
         return tuple(_RG_TUNED[key])
     cdiv = lambda a, b: (a + b - 1) // b
     best, best_t = None, None

@@ -35,13 +35,14 @@ def L():
     return ops
 
 
-def _geoms(tiles, ntr_tiles=0, mt_ok=True):
+def _geoms(tiles, ntr_tiles=0, mt_ok=True, mt4=False):
+    """mt4: also the 128-token tiles (K = 320 only)"""
     out = []
-    for mt in (1, 2):
-        if mt == 2 and not mt_ok:
+    for mt in (1, 2, 4):
+        if (mt == 2 and not mt_ok) or (mt == 4 and not mt4):
             continue
         for nt in (1, 2, 3, 4):
-            if mt == 2 and nt > 2:
+            if mt >= 2 and nt > 2:
                 continue
             for nw in range(1, (5 if nt >= 3 else 8) + 1):
                 if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0:
@@ -74,7 +75,7 @@ def test_rowgemm_every_geometry(L, K):
     ref = x.float() @ w.float().t() + b
     wp, bp = L.pack_rowgemm(w.to(DEV), b.to(DEV))
     seen = 0
-    for sched in _geoms(N // 32):
+    for sched in _geoms(N // 32, mt4=(K == 320)):
         out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
         for order in (0, 1):
             L.run(L.rowgemm(x.to(DEV), wp, out, M=M, K=K, Nout=N, ldx=K, ldo=N, bias=bp, sched=sched, order=order))
@@ -146,7 +147,7 @@ def test_rowgemm_geglu_with_layernorm(L, M, C):
     torch.cuda.synchronize()
     check(out, ref, tol=3e-3, what=f"LN + GEGLU {M}x{C}")
     if C == 320:
-        for sched in ((8, 2, 2), (4, 2, 2), (5, 4, 1), (8, 1, 1), (4, 1, 2)):
+        for sched in ((8, 2, 2), (4, 2, 2), (5, 4, 1), (8, 1, 1), (4, 1, 2), (5, 2, 4), (8, 1, 4), (4, 2, 4), (5, 1, 4)):
             L.run(L.rowgemm(x.to(DEV), wp, out, M=M, K=C, Nout=8 * C, ldx=C, ldo=4 * C, bias=bp, pro=1, eps=1e-5, epi=1, sched=sched))
             torch.cuda.synchronize()
             check(out, ref, tol=3e-3, what=f"LN + GEGLU geometry {sched}")
@@ -164,6 +165,8 @@ def test_rowgemm_qkv_with_transposed_v(L, B, T, C):
     qk = torch.empty(M, 2 * C, dtype=torch.float16, device=DEV)
     vt = torch.full((B, C, ldvt), 7.0, dtype=torch.float16, device=DEV)
     geoms = [None] + [g for g in _geoms(3 * C // 32, C // 32, mt_ok=(T % 64 == 0))][:10]
+    if C == 320 and T % 128 == 0:
+        geoms += [(5, 1, 4), (5, 2, 4), (2, 1, 4), (1, 2, 4)]
     for sched in geoms:
         qk.zero_(); vt.fill_(7.0)
         L.run(L.rowgemm(x.to(DEV), wp, qk, M=M, K=C, Nout=3 * C, ldx=C, ldo=2 * C, bias=bp, pro=1, eps=1e-5, T=T, out_t=vt, ntr=C,
@@ -216,6 +219,49 @@ def test_rowgemm_groupnorm_statistics_of_the_output(L, B, T, K, C, choff2, Ccat)
     check(y, gref, what="gn_apply from rowgemm statistics")
 
 
+def test_rowgemm_128_token_tiles(L):
+    """MT = 4 (K = 320): GroupNorm prologue, bias, residual (fetched in the epilogue here) and output statistics; ragged M for the
+    plain form; the same results as the default geometry."""
+    B, T, C, G = 2, 4096, 320, 32
+    M = B * T
+    x0 = rnd(M, C, seed=71)
+    x = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    acc = torch.zeros(B, G, 2, dtype=torch.int64, device=DEV)
+    wi = L.pack_linear(torch.eye(C).half().to(DEV))
+    op, keep = L.igemm(x0.to(DEV), wi, x, M=M, Nout=C, C1=C, ldx1=C, CinP=wi.shape[1], ldo=C, tile=2, variant=1)
+    assert L.gn_target(op, acc.data_ptr(), T=T, G=G, cpg=C // G, choff=0)
+    L.run((op, keep + (acc,)))
+    w, b, r = rnd(C, C, seed=72, scale=C ** -0.5), rnd(C, seed=73).float(), rnd(M, C, seed=74)
+    gm, bt = (1 + 0.2 * rnd(C, seed=75).float()).half(), (0.2 * rnd(C, seed=76).float()).half()
+    xn = F.group_norm(x0.float().view(B, T, C).permute(0, 2, 1), G, gm.float(), bt.float(), 1e-6).permute(0, 2, 1).reshape(M, C)
+    ref = (xn @ w.float().t() + b).half().float() + r.float()
+    wp, bp = L.pack_rowgemm(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV))
+    outs = []
+    for sched in ((5, 1, 1), (5, 1, 4), (5, 2, 4), (2, 1, 4)):
+        out = torch.zeros(M, C, dtype=torch.float16, device=DEV)
+        acc2 = torch.zeros(B, G, 2, dtype=torch.int64, device=DEV)
+        op, keep = L.rowgemm(x, wp, out, M=M, K=C, Nout=C, ldx=C, ldo=C, bias=bp, res=r.to(DEV), ldr=C, pro=2, eps=1e-6, T=T, G=G,
+                             gn_acc_ptr=acc.data_ptr(), sched=sched)
+        assert L.gn_target(op, acc2.data_ptr(), T=T, G=G, cpg=C // G, choff=0)
+        L.run((op, keep + (acc2,)))
+        torch.cuda.synchronize()
+        check(out, ref, tol=3e-3, what=f"GN + linear + residual, geometry {sched}")
+        outs.append((out.clone(), acc2.clone()))
+    for o, a2 in outs[1:]:
+        assert torch.equal(o, outs[0][0]), "128-token tiles must reproduce the default geometry bit for bit"
+        # (the statistics are summed in fp32 per block before the fixed-point atomics: another tile shape, another rounding)
+        d = (a2 - outs[0][1]).abs().double() / outs[0][1].abs().double().clamp_min(1.0)
+        assert d.max().item() < 1e-4
+    # ragged M (not a multiple of 128), plain linear
+    Mr = 1000
+    xr, wr = rnd(Mr, C, seed=77), rnd(960, C, seed=78, scale=C ** -0.5)
+    wpr, _ = L.pack_rowgemm(wr.to(DEV))
+    o = torch.zeros(Mr, 960, dtype=torch.float16, device=DEV)
+    L.run(L.rowgemm(xr.to(DEV), wpr, o, M=Mr, K=C, Nout=960, ldx=C, ldo=960, sched=(5, 2, 4)))
+    torch.cuda.synchronize()
+    check(o, xr.float() @ wr.float().t(), what="ragged M, 128-token tiles")
+
+
 def test_rowgemm_rejects_bad_arguments(L):
     from live2diff_amd import _lib
     x, w = rnd(64, 64).to(DEV), rnd(64, 64).to(DEV)
@@ -227,3 +273,5 @@ def test_rowgemm_rejects_bad_arguments(L):
         L.run(L.rowgemm(x, wp, out, M=64, K=64, Nout=64, ldx=64, ldo=60))                        # ldo % 8
     with pytest.raises(_lib.L2DError):
         L.run(L.rowgemm(x, wp, out, M=64, K=64, Nout=64, ldx=64, ldo=64, pro=2, T=48, G=32, gn_acc_ptr=out.data_ptr()))   # T % 32
+    with pytest.raises(_lib.L2DError):
+        L.run(L.rowgemm(x, wp, out, M=64, K=64, Nout=64, ldx=64, ldo=64, sched=(2, 1, 4)))      # 128-token tiles: K = 320 only

@@ -73,7 +73,8 @@ def main():
     def fits(op, g):
         nw, nt, mt = g
         tiles, ntr, T = op.i[2] // 32, op.i[15], op.i[9]
-        if tiles % (nw * nt) or ntr % (nw * nt) or nw > (5 if nt >= 3 else 8) or (mt == 2 and (nt > 2 or T % 64 or op.i[0] < 2048)):
+        if tiles % (nw * nt) or ntr % (nw * nt) or nw > (5 if nt >= 3 else 8) or not ops._rowgemm_mt_ok(mt, nt, op.i[1], T) or \
+                (mt >= 2 and op.i[0] < 1024 * mt):
             return False
         return ops._rowgemm_lds(op.i[1], nw, nt, mt, op.i[6], op.i[7], ntr * 32, bool(op.p[9])) <= 163840
 
@@ -82,7 +83,7 @@ def main():
         if op.kind == _lib.OP_ROWGEMM:
             d = per_shape[shape_key(op)].setdefault(("default", op.i[12], op.i[13], op.i[14]), [])
             d.append(t)
-    cands = [(nw, nt, mt) for mt in (1, 2) for nt in (1, 2, 3, 4) for nw in (1, 2, 3, 4, 5, 6, 8) if not (mt == 2 and nt > 2) and nw <= (5 if nt >= 3 else 8)]
+    cands = [(nw, nt, mt) for mt in (1, 2, 4) for nt in (1, 2, 3, 4) for nw in (1, 2, 3, 4, 5, 6, 8) if not (mt >= 2 and nt > 2) and nw <= (5 if nt >= 3 else 8)]
     for g in cands:
         def mod(c, g=g):
             if fits(c, g):
