@@ -30,6 +30,7 @@ struct PConvArgs {
     const h16 *res;
     h16 *out;
     int B, H, W, C1, C2, ldx1, ldx2, CinP, Nout, ldo, ldr, ldrb, rows_per_bias;
+    int epi;                       // as igemm.hip: 0 none, 2 SiLU, 3 ReLU, 5 GELU (fp32, before the fp16 rounding), 4 ReLU after the residual add
     int npx, npy, ntn, nwg, order;
     unsigned long long *gn1, *gn2;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
@@ -192,7 +193,17 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(PConvArgs a) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int row = (wm * MI + j) * 16 + li;
-            const f32x4 v = acc[i][j] + bv;
+            f32x4 v = acc[i][j] + bv;
+            if (a.epi == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (a.epi == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = l2d_silu(v[r]);
+            } else if (a.epi == 5) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = l2d_gelu(v[r]);
+            }
             h16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void pconv_kernel(PConvArgs a) {
         const int cidx = it * 256 + tid, row = cidx / CPRN, cc = cidx % CPRN;
         h16x8 v = l2d_ld8(ot + row * pitch + cc * 8);
         if (a.res) v = v + resv[it];
+        if (a.epi == 4) v = __builtin_elementwise_max(v, l2d_zero8());          // relu(conv + skip), TAESD blocks
         l2d_st8(a.out + mrow(row) * a.ldo + n0 + cc * 8, v);
         if (gn) {
 #pragma unroll
@@ -271,7 +283,7 @@ int l2d_launch_pconv(const l2d_op *op, hipStream_t s) {
     a.gn1 = (unsigned long long *)op->p[9]; a.gn2 = (unsigned long long *)op->p[10];
     a.C1 = op->i[1]; a.C2 = op->i[2]; a.ldx1 = op->i[3]; a.ldx2 = op->i[4]; a.CinP = op->i[5]; a.B = op->i[6];
     a.H = op->i[7]; a.W = op->i[8]; a.Nout = op->i[14]; a.ldo = op->i[15]; a.ldr = op->i[16]; a.ldrb = op->i[17];
-    a.rows_per_bias = op->i[18];
+    a.rows_per_bias = op->i[18]; a.epi = op->i[19];
     const int PH = op->i[9], PW = op->i[10];
     a.order = op->i[11] ? 1 : 0;
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
@@ -280,7 +292,7 @@ int l2d_launch_pconv(const l2d_op *op, hipStream_t s) {
     if (!a.x1 || !a.w || !a.out || !a.zero || !pok || a.B <= 0 || a.H <= 0 || a.W <= 0 || (a.H % PH) || (a.W % PW) ||
         a.C1 <= 0 || (a.C1 % 64) || (a.C2 % 64) || (a.C2 > 0 && !a.x2) || a.CinP != a.C1 + a.C2 || (a.Nout % 64) || a.Nout <= 0 ||
         (a.ldx1 % 8) || a.ldx1 < a.C1 || (a.C2 > 0 && ((a.ldx2 % 8) || a.ldx2 < a.C2)) || (a.ldo % 8) || (a.res && (a.ldr % 8)) ||
-        (a.rowbias && (a.ldrb <= 0 || a.rows_per_bias <= 0)) ||
+        (a.rowbias && (a.ldrb <= 0 || a.rows_per_bias <= 0)) || a.epi < 0 || a.epi > 5 || a.epi == 1 || (a.epi == 4 && !a.res) ||
         (((unsigned long long)a.x1 | (unsigned long long)a.x2 | (unsigned long long)a.w | (unsigned long long)a.out |
           (unsigned long long)a.res | (unsigned long long)a.bias | (unsigned long long)a.rowbias) & 15)) {
         l2d_set_error("pconv(tag %d): invalid arguments (B=%d H=%d W=%d C1=%d C2=%d CinP=%d Nout=%d patch %dx%d)", op->tag, a.B, a.H,
@@ -296,7 +308,8 @@ int l2d_launch_pconv(const l2d_op *op, hipStream_t s) {
     }
     a.npx = a.W / PW; a.npy = a.H / PH; a.ntn = a.Nout / 64;
     a.nwg = a.B * a.npx * a.npy * a.ntn;
-    if ((long long)a.B * a.H * a.W >= (1ll << 31) / 4096) {
+    // (pixel indices are 32-bit, every element offset is formed in 64 bits)
+    if ((long long)a.B * a.H * a.W >= (1ll << 28) || (long long)a.nwg >= (1ll << 30)) {
         l2d_set_error("pconv(tag %d): tensor too large for the kernel's index arithmetic", op->tag);
         return L2D_EINVAL;
     }

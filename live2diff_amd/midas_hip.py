@@ -243,6 +243,11 @@ class HipMidas:
             n = wt.shape[0]
             ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
             out = ar.alloc(B * ho * wo * n)
+            patch = ops.pconv_patch(B, h, w, n, C) if (stride == 1 and wt.shape[1] == 9 * C) else None
+            if patch is not None:      # decoder convs at the upper resolutions: patch-resident 3x3 conv (csrc/pconv.hip)
+                op = add(ops.pconv(x, wt, out, B=B, H=h, W=w, C1=C, ldx1=C, CinP=C, Nout=n, ldo=n, patch=patch,
+                                   bias=(W.get(name + ".b") if bias else None), res=res, ldr=(n if res is not None else 0), epi=epi))
+                return out, op, ho, wo
             op = gemm(x, wt, out, M=B * ho * wo, Nout=n, C1=C, ldx1=C, CinP=wt.shape[1] // 9, ldo=n, bias=(W.get(name + ".b") if bias else None),
                       res=res, ldr=(n if res is not None else 0), taps=9, B=B, Hin=h, Win=w, Hout=ho, Wout=wo, stride=stride, epi=epi,
                       pad_same=same)
@@ -252,7 +257,7 @@ class HipMidas:
             """GroupNorm(32) (+ ReLU / + shortcut + ReLU) of a tensor just written by `op_prod` (statistics from its epilogue)."""
             out = ar.alloc(B * T * C)
             acc_ptr = st.gn_acc.data_ptr() + st.gn_layers * B * G * 2 * 8
-            if st.gn_layers < st.gn_acc.shape[0] and ops.igemm_gn_target(op_prod, acc_ptr, T=T, G=G, cpg=C // G, choff=0):
+            if st.gn_layers < st.gn_acc.shape[0] and ops.gn_target(op_prod, acc_ptr, T=T, G=G, cpg=C // G, choff=0):
                 st.gn_layers += 1
                 add(ops.gn_apply(x, None, W[name + ".g"], W[name + ".beta"], out, eps=1e-5, silu=act, B=B, T=T, C1=C, ld1=C, G=G, nchunk=0,
                                  acc_ptr=acc_ptr, res=res))

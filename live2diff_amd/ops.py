@@ -220,8 +220,9 @@ def pconv_patch(B: int, H: int, W: int, Nout: int, C1: int, C2: int = 0):
 
 
 def pconv(x1, w, out, *, B, H, W, C1, ldx1, CinP, Nout, ldo, patch, x2=None, C2=0, ldx2=0, bias=None, rowbias=None, ldrb=0,
-          rows_per_bias=0, res=None, ldr=0, order=None):
-    """3x3 stride-1 conv, activation patch resident in LDS (csrc/pconv.hip); `w` = pack_conv3x3 weights (as igemm)."""
+          rows_per_bias=0, res=None, ldr=0, order=None, epi=0):
+    """3x3 stride-1 conv, activation patch resident in LDS (csrc/pconv.hip); `w` = pack_conv3x3 weights (as igemm).
+    epi as igemm: 0 none, 2 SiLU, 3 ReLU, 5 GELU, 4 ReLU after the residual add."""
     op = L2dOp()
     op.kind = _lib.OP_PCONV
     zp = zero_page(x1.device)
@@ -232,7 +233,7 @@ def pconv(x1, w, out, *, B, H, W, C1, ldx1, CinP, Nout, ldo, patch, x2=None, C2=
     if order is None:
         order = int(Nout * 9 * CinP > B * H * W * (C1 + C2))
     vals = {1: C1, 2: C2, 3: ldx1, 4: ldx2, 5: CinP, 6: B, 7: H, 8: W, 9: patch[0], 10: patch[1], 11: order, 14: Nout, 15: ldo,
-            16: ldr, 17: ldrb, 18: rows_per_bias}
+            16: ldr, 17: ldrb, 18: rows_per_bias, 19: epi}
     for j, v in vals.items():
         op.i[j] = int(v)
     return op, (x1, x2, w, bias, rowbias, res, out, zp)

@@ -127,6 +127,12 @@ class HipTinyVAE:
             ldo = max(4, cout)                                   # 3-channel image rows are stored 4 wide
             out = ar.alloc(B * ho * wo * ldo)
             M, Kp = B * ho * wo, wt.shape[1]
+            patch = ops.pconv_patch(B, h, w, cout, C) if (stride == 1 and not ups and Kp == 9 * C) else None
+            if patch is not None:
+                # 64 -> 64 convs at the upper resolutions: the activation patch stays in LDS for all nine taps (csrc/pconv.hip)
+                pl.append(*ops.pconv(x, wt, out, B=B, H=h, W=w, C1=C, ldx1=C, CinP=C, Nout=cout, ldo=ldo, patch=patch,
+                                     bias=W.get(name + "bias"), res=res, ldr=(cout if res is not None else 0), epi=epi))
+                return out, cout, ho, wo
             tile, S, variant = ops.igemm_schedule(M, cout, Kp, 1, epi, 9)
             pl.append(*ops.igemm(x, wt, out, M=M, Nout=cout, C1=C, ldx1=C, CinP=Kp // 9, ldo=ldo, bias=W.get(name + "bias"),
                                  res=res, ldr=(cout if res is not None else 0), taps=9, B=B, Hin=h, Win=w, Hout=ho, Wout=wo,

@@ -125,3 +125,33 @@ def test_pconv_rejects_bad_arguments(L):
         L.run(L.pconv(x, w, out, B=1, H=8, W=16, C1=64, ldx1=64, CinP=64, Nout=64, ldo=64, patch=(8, 12)))      # no such patch
     with pytest.raises(_lib.L2DError):
         L.run(L.pconv(x, w, out, B=1, H=8, W=16, C1=64, ldx1=64, CinP=64, Nout=64, ldo=60, patch=(8, 16)))      # ldo % 8
+
+
+@pytest.mark.parametrize("B,H,W,C,N,patch", [(1, 128, 128, 64, 64, (8, 16)), (2, 48, 64, 256, 128, (8, 8)), (8, 32, 32, 64, 64, (4, 8))])
+def test_pconv_activation_epilogues(L, B, H, W, C, N, patch):
+    """The epilogue modes the TAESD / DPT decoder convs use (as igemm): ReLU, SiLU, GELU in fp32 before the fp16 rounding;
+    relu(conv(x) + skip) with the add in fp16 after the conv output is rounded (the reference's fp16 graph)."""
+    x = rnd(B, H, W, C, seed=21)
+    w = rnd(N, C, 3, 3, seed=22, scale=(9 * C) ** -0.5)
+    b = rnd(N, seed=23).float()
+    r = rnd(B * H * W, N, seed=24)
+    conv = (F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1).reshape(B * H * W, N)
+    refs = {0: conv, 3: F.relu(conv), 2: F.silu(conv), 5: F.gelu(conv), 4: F.relu(conv.half().float() + r.float())}
+    wp = L.pack_conv3x3(w.to(DEV))
+    xd = x.to(DEV).reshape(B * H * W, C)
+    for epi, ref in refs.items():
+        out = torch.zeros(B * H * W, N, dtype=torch.float16, device=DEV)
+        L.run(L.pconv(xd, wp, out, B=B, H=H, W=W, C1=C, ldx1=C, CinP=C, Nout=N, ldo=N, patch=patch, bias=b.to(DEV),
+                      res=(r.to(DEV) if epi == 4 else None), ldr=(N if epi == 4 else 0), epi=epi))
+        torch.cuda.synchronize()
+        e = relerr(out, ref)
+        assert torch.isfinite(out.float()).all() and e <= 2e-3, f"pconv epi {epi}: rel-L2 {e:.3e}"
+        # the implicit-GEMM kernel with the same epilogue mode gives the same tensor up to summation order
+        out_i = torch.zeros_like(out)
+        L.run(L.igemm(xd, wp, out_i, M=B * H * W, Nout=N, C1=C, ldx1=C, CinP=C, ldo=N, bias=b.to(DEV), taps=9, B=B, Hin=H, Win=W,
+                      Hout=H, Wout=W, epi=epi, res=(r.to(DEV) if epi == 4 else None), ldr=(N if epi == 4 else 0), tile=2, variant=1))
+        torch.cuda.synchronize()
+        assert relerr(out, out_i) <= 1e-3, f"pconv vs igemm, epi {epi}"
+    from live2diff_amd import _lib
+    with pytest.raises(_lib.L2DError):               # relu-after-add needs the skip tensor
+        L.run(L.pconv(xd, wp, out, B=B, H=H, W=W, C1=C, ldx1=C, CinP=C, Nout=N, ldo=N, patch=patch, epi=4))
