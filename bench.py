@@ -238,6 +238,56 @@ def baseline_metric() -> str:
         return "frames/sec @512\u00d7512, 2 denoise steps; per-step latency; 1/2/4/8 GPU"
 
 
+def multi_stream_sweep(unet, cfg, args, dev, N, smax, frames=24):
+    """Serving mode, informational: S independent frame streams on ONE GPU -- each a full UNet step of this workload with its
+    own plan buffers, inputs and KV caches, all sharing the one packed-weight replica, each replayed from its own hipGraph on
+    its own HIP stream.  A single stream is a chain of ~480 latency-bound launches that leaves most CUs idle most of the time;
+    concurrent streams fill those gaps.  Reports ms per round (one frame of every stream = the per-stream frame latency) and
+    aggregate frames/s for S = 1 .. smax.  `value` of the bench line stays the single-stream figure."""
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    h, w, L = args.height // 8, args.width // 8, cfg.window_size
+    g = torch.Generator(device=dev).manual_seed(1234)
+    fns, keep = [], []
+    for _ in range(smax):
+        u = HipStreamingUNet(unet, cfg, h, w, N, device=dev, use_graph=True)       # shares unet's packed weights
+        kvs = u.prepare_cache(N)
+        for c in kvs:
+            c.normal_(generator=g)
+        x = torch.randn(N, 4, 1, h, w, device=dev, generator=g).half()
+        dd = torch.randn(N, 4, 1, h, w, device=dev, generator=g).half()
+        enc = torch.randn(N, 77, cfg.cross_attention_dim, device=dev, generator=g).half()
+        ts = torch.tensor([399, 199, 99, 19][:N], device=dev)
+        bias = torch.zeros(N, L, device=dev).half()
+        pe = torch.arange(L, device=dev).repeat(N, 1)
+        upd = torch.full((N,), L - 1, device=dev, dtype=torch.int64)
+        keep.append((u, kvs))
+        fns.append(lambda u=u, x=x, dd=dd, enc=enc, ts=ts, bias=bias, pe=pe, upd=upd, kvs=kvs: u(
+            x, ts, encoder_hidden_states=enc, temporal_attention_mask=bias, depth_sample=dd, kv_cache=kvs, pe_idx=pe, update_idx=upd))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(smax)]
+    for f in fns:                                   # first run direct (kernel attributes), second captures the graph
+        f(); f(); f()
+    torch.cuda.synchronize()
+    out = {"note": "S independent streams per GPU (own KV caches / plan buffers, shared weights, one hipGraph and HIP stream each); "
+                   "ms_per_round = one frame of every stream"}
+    for S in range(1, smax + 1):
+        def rnd():
+            for f, st in zip(fns[:S], streams[:S]):
+                with torch.cuda.stream(st):
+                    f()
+        for _ in range(4):
+            rnd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            rnd()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        out[f"S{S}"] = {"ms_per_round": round(ms, 3), "frames_per_s": round(S * 1e3 / ms, 2)}
+    del fns, keep
+    torch.cuda.empty_cache()
+    return out
+
+
 def pipeline_whole_frame(unet, cfg, args, dev, N, sink, kv):
     """The reference's published FPS definition (README.md:43-50 / test.py:201-205), measured through THIS repo's pipeline
     class: `StreamAnimateDiffusionDepth.__call__` per frame = preprocess + encode_image (TAESD encode, noise draw + add_noise)
@@ -329,6 +379,7 @@ def main():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--sink", type=int, default=0, help="warm-up / sink slots (default 8; 4 with --window 12 = BASELINE configs[0])")
     ap.add_argument("--breakdown", type=int, default=1)
+    ap.add_argument("--multi-stream", type=int, default=4, help="also measure 1..S independent streams on one GPU (informational; 0 = off)")
     ap.add_argument("--whole-frame", type=int, default=1, help="also time VAE encode x2 + depth detector and glue + UNet + VAE decode (informational)")
     ap.add_argument("--per-op", type=str, default="", help="write a per-launch timing CSV to this path")
     ap.add_argument("--dump-plan", type=str, default="", help="write the stream plan (one row per launch) as CSV")
@@ -455,6 +506,13 @@ def main():
         except Exception as e:  # noqa: BLE001  -- informational figure: never fails the benchmark
             whole = {"error": repr(e)}
 
+    multi = None
+    if rank == 0 and world == 1 and args.multi_stream > 1:
+        try:
+            multi = multi_stream_sweep(unet, cfg, args, dev, N, args.multi_stream)
+        except Exception as e:  # noqa: BLE001  -- informational figure: never fails the benchmark
+            multi = {"error": repr(e)}
+
     # CPU-baseline / parity leg, part 1 (before the per-kernel replays below, which run each kernel family out of context
     # and leave stale rows in the KV caches): same state for both legs = snapshot of (inputs, caches, ring buffer), then
     # ONE more GPU frame from exactly that state; the oracle starts from the snapshot after the JSON fields are assembled.
@@ -470,7 +528,7 @@ def main():
         "metric": baseline_metric(),
         "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic", "latency_per_step": latency, "whole_frame": whole,
+        "dtype": "f16", "data": "synthetic", "latency_per_step": latency, "whole_frame": whole, "streams_per_gpu": multi,
         "per_rank_frames_per_s": per_rank_fps,
         "config": {"workload": f"{WORKLOAD_NAMES.get((args.height, args.width, N, args.window), 'custom (not a BASELINE config)')}: "
                                f"{args.height}x{args.width} image ({h}x{w} latent), {N} denoise steps, "

@@ -97,6 +97,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
     const int b = blockIdx.y;
+    // The first trip's operands (gamma, beta, four rows of x) do not depend on the statistics: they are requested HERE, so that
+    // the launch is one memory round trip deep (statistics, parameters and data in flight together) instead of three
+    // dependent ones -- these launches move 0.2-5 MB and sit on the latency floor.
+    const int t0 = blockIdx.x * pix_per_block, t1 = min(a.T, t0 + pix_per_block);
+    const int cols = min(nvc, 256), PR = 256 / cols;
+    const int prow = tid / cols, vcl = tid - prow * cols;
+    const bool act0 = prow < PR && vcl < nvc;
+    h16x8 gm0 = l2d_zero8(), bt0 = l2d_zero8(), v0[4];
+    if (act0) {
+        gm0 = l2d_ld8(a.gamma + vcl * 8);
+        bt0 = l2d_ld8(a.beta + vcl * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = t0 + prow + u * PR;
+            v0[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vcl) : l2d_zero8();
+        }
+    }
     if (a.nchunk == 0) {   // statistics arrive as integers in units of 2^-20 (sum) and 2^-12 (sum of squares)
         const int g = tid & 63, part = tid >> 6;
         float s = 0.f, q = 0.f;
@@ -130,14 +147,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
         s_rstd[tid] = rsqrtf(var + a.eps);
     }
     __syncthreads();
-    const int t0 = blockIdx.x * pix_per_block, t1 = min(a.T, t0 + pix_per_block);
-    const int cols = min(nvc, 256), PR = 256 / cols;
-    const int prow = tid / cols, vcl = tid - prow * cols;
     for (int cb = 0; cb < nvc; cb += cols) {
         int vc = cb + vcl;
         if (prow >= PR || vc >= nvc) continue;
         float sc[8], sh[8];
-        h16x8 gm = l2d_ld8(a.gamma + vc * 8), bt = l2d_ld8(a.beta + vc * 8);
+        h16x8 gm = gm0, bt = bt0;
+        if (cb) { gm = l2d_ld8(a.gamma + vc * 8); bt = l2d_ld8(a.beta + vc * 8); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int g = (vc * 8 + e) / cpg;
@@ -146,10 +161,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
         }
         for (int t = t0 + prow; t < t1; t += 4 * PR) {     // 4 rows per trip, loads first (see gn_stats)
             h16x8 v[4];
+            if (cb == 0 && t == t0 + prow) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int tt = t + u * PR;
-                v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
+                for (int u = 0; u < 4; ++u) v[u] = v0[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int tt = t + u * PR;
+                    v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

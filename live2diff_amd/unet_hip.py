@@ -97,7 +97,10 @@ class HipStreamingUNet:
                  denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
                  tattn_variant: int = 0, text_len: int = 77, fresh_output: bool = False):
         """height/width are LATENT sizes (image / 8). `state_dict` uses the reference key names; it may also be the
-        path of a packed-weight file written by `save_packed`."""
+        path of a packed-weight file written by `save_packed`, or ANOTHER HipStreamingUNet of the same
+        configuration and latent size whose packed weights this instance then shares (read-only replicas are per GPU, not per
+        stream: several independent frame streams on one GPU -- each with its own plan buffers and KV caches, each on its own
+        HIP stream -- fill each other's launch gaps)."""
         assert cfg.num_heads == 8 and cfg.temporal_heads == 8
         assert height % 8 == 0 and width % 8 == 0, "latent size must be divisible by 8 (3 down-samplings, T%4==0)"
         self.cfg, self.h, self.w, self.N = cfg, height, width, denoising_steps_num
@@ -115,7 +118,13 @@ class HipStreamingUNet:
         self.config = SimpleNamespace(in_channels=cfg.in_channels)      # read by the reference wrapper (:524)
         self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()   # raises unless a gfx950 is present
         self.mm_layout = motion_module_layout(cfg, height, width)
-        if isinstance(state_dict, (str, os.PathLike)):
+        if isinstance(state_dict, HipStreamingUNet):
+            o = state_dict
+            if (o.cfg, o.h, o.w, o.device) != (cfg, self.h, self.w, self.device):
+                raise ValueError("shared packed weights need the same configuration, latent size and device")
+            self.W, self.temb_offsets, self.text_offsets = o.W, o.temb_offsets, o.text_offsets
+            self.n_map_blocks, self.temb_total, self.text_total, self.text_kp = o.n_map_blocks, o.temb_total, o.text_total, o.text_kp
+        elif isinstance(state_dict, (str, os.PathLike)):
             self._load_packed(state_dict)          # a file written by save_packed(): skips the packing pass
         else:
             self._pack_weights(state_dict)

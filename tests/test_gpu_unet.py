@@ -437,3 +437,51 @@ def test_cfg2_stream_batch_rows_are_independent(cfg2_unet):
     assert torch.equal(b_.flip(0), a), rel(b_.flip(0), a)      # same tiles, same order: bit-identical
     for c, b in zip(kv, before):
         c.copy_(b)
+
+
+def test_cfg2_concurrent_streams_share_weights(cfg2_unet):
+    """Serving mode: three more UNet instances built FROM the first one share its packed weights and own
+    everything else (plan buffers, statistics accumulators, split-K counters, KV caches).  Four streams with different inputs
+    run concurrently on four HIP streams (hipGraph replay), several rounds; every stream's outputs and caches are bit-identical
+    to the same stream run alone on the first instance -- nothing leaks between concurrent plans."""
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    unet, kv, i = cfg2_unet
+    before = [c.clone() for c in kv]
+    S, rounds = 4, 3
+    g = torch.Generator(device=DEV).manual_seed(77)
+    ins = []
+    for s in range(S):
+        j = dict(i)
+        j["x"] = torch.randn(i["x"].shape, generator=g, device=DEV, dtype=torch.float16)
+        j["d"] = torch.randn(i["d"].shape, generator=g, device=DEV, dtype=torch.float16)
+        j["enc"] = torch.randn(i["enc"].shape, generator=g, device=DEV, dtype=torch.float16)
+        ins.append(j)
+    # reference: every stream alone, serially, on the original instance (its own cache copy, `rounds` frames)
+    want = []
+    for s in range(S):
+        kvs = [b.clone().roll(s + 1, dims=2) for b in before]          # a different cache content per stream
+        outs = [_step(unet, kvs, ins[s]) for _ in range(rounds)]
+        want.append((outs, [c.clone() for c in kvs]))
+        del kvs
+    # concurrent: S instances sharing the weights, one HIP stream each
+    units = [HipStreamingUNet(unet, unet.cfg, unet.h, unet.w, unet.N, device=DEV, use_graph=True) for _ in range(S)]
+    assert all(u.W is unet.W for u in units)
+    kvss = [[b.clone().roll(s + 1, dims=2) for b in before] for s in range(S)]
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    torch.cuda.synchronize()
+    got = [[] for _ in range(S)]
+    for r in range(rounds):
+        for s in range(S):
+            with torch.cuda.stream(streams[s]):
+                j = ins[s]
+                o = units[s](j["x"], j["ts"], encoder_hidden_states=j["enc"], temporal_attention_mask=j["bias"], depth_sample=j["d"],
+                             kv_cache=kvss[s], pe_idx=j["pe"], update_idx=j["upd"])
+                got[s].append(o["sample"].clone())
+    torch.cuda.synchronize()
+    for s in range(S):
+        for r in range(rounds):
+            assert torch.equal(got[s][r], want[s][0][r]), f"stream {s} frame {r}: {rel(got[s][r], want[s][0][r]):.3e}"
+        for a, b in zip(kvss[s], want[s][1]):
+            assert torch.equal(a, b), f"stream {s}: KV cache differs"
+    for c, b in zip(kv, before):
+        c.copy_(b)

@@ -445,3 +445,21 @@ def test_frame_filter_matches_reference_trace():
         f.set_threshold(float(thr)); f.set_max_skip_frame(float(ms))
         got = [0 if f(x) is None else 1 for x in frame_sequence()]
         assert got == dec, key
+
+
+def test_unet_instances_can_share_packed_weights(dry_run):
+    """A second HipStreamingUNet built FROM a first one (serving several streams per GPU) shares its packed weights by reference
+    and refuses another latent size / configuration (the packing depends on both)."""
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config()
+    u = HipStreamingUNet(random_state_dict(cfg, dtype=torch.float16), cfg, 16, 16, 2, device="cpu")
+    v = HipStreamingUNet(u, cfg, 16, 16, 2, device="cpu", use_graph=True)
+    assert v.W is u.W and v.temb_offsets is u.temb_offsets
+    n = len(v._plan("stream", v.prepare_cache(2)).pl)
+    assert n == len(u._plan("stream", u.prepare_cache(2)).pl)
+    with pytest.raises(ValueError):
+        HipStreamingUNet(u, cfg, 8, 8, 2, device="cpu")
+    with pytest.raises(ValueError):
+        HipStreamingUNet(u, tiny_config(window_size=12, sink_size=4), 16, 16, 2, device="cpu")
