@@ -124,9 +124,14 @@ def tattn_variant_sweep(unet, reps=5, variants=(1, 13)):
     out = {v: [] for v in lists}
     for _ in range(3):
         for v, pl in lists.items():
-            pl.time_ms(1)
-            out[v].append(pl.time_ms(reps))
-    return {f"v{v}": round(min(t), 4) for v, t in out.items()}
+            if out[v] is None:
+                continue
+            try:
+                pl.time_ms(1)
+                out[v].append(pl.time_ms(reps))
+            except _lib.L2DError:       # a forced variant some level of this resolution cannot take (ring: T % 8, SD widths)
+                out[v] = None
+    return {f"v{v}": (round(min(t), 4) if t else None) for v, t in out.items()}
 
 
 def op_dims(op, kinds):
