@@ -359,6 +359,58 @@ class StreamAnimateDiffusionDepth:
         self._device_step.load_buffers(self.x_t_latent_buffer, self.depth_latent_buffer)
         return self._device_step
 
+    # ------------------------------------------------------------------ pipelined frames (opt-in; not in the reference)
+    def enable_frame_pipelining(self):
+        """Opt in to `push(frame)` / `pop()`.  The reference's `__call__` is synchronous: encode, depth path, UNet and decode of a
+        frame run back to back and the call ends with a global synchronize (:643-654), although everything in front of the UNet
+        -- preprocess, TAESD encode + noise, 384x384 resize, depth detector, min-max / resize, TAESD encode of the depth map --
+        depends on the incoming frame only.  `push(frame)` starts that part on a second HIP stream and returns; `pop()` runs the
+        UNet step and the decode of the OLDEST pushed frame on the caller's stream and returns its output.  A caller that
+        pushes frame t + 1 before it pops frame t overlaps the two (the UNet step is a chain of latency-bound launches that
+        leaves most CUs idle), at the price of holding one frame more in flight.  Results are those of
+        `__call__` on the same frames, bit for bit: needs the device step (its re-noising draws from the plan's own
+        counter-based generator, so the order of the torch.randn draws of `encode_image` is all that is left on the host
+        generator and it is the same in both modes); the near-duplicate frame filter is not consulted in this mode."""
+        import collections
+        if getattr(self, "_device_step", None) is None:
+            raise ValueError("enable_frame_pipelining needs enable_device_step() first")
+        self._pre_stream = torch.cuda.Stream(device=self.device)
+        self._pending = collections.deque()
+
+    def push(self, x: Union[torch.Tensor, np.ndarray]) -> None:
+        cur = torch.cuda.current_stream()
+        x = self.image_processor.preprocess(x, self.height, self.width).to(device=self.device, dtype=self.dtype)
+        self._pre_stream.wait_stream(cur)                     # the frame is ready; earlier consumers of the side buffers are done
+        with torch.cuda.stream(self._pre_stream):
+            x_t_latent = self.encode_image(x)
+            depth_latent = self.encode_depth(x)
+            ev = torch.cuda.Event()
+            ev.record(self._pre_stream)
+        if x.is_cuda:
+            x.record_stream(self._pre_stream)
+        self._pending.append((x_t_latent, depth_latent, ev))
+
+    def pop(self) -> torch.Tensor:
+        if not self._pending:
+            raise RuntimeError("pop() without a pushed frame")
+        x_t_latent, depth_latent, ev = self._pending.popleft()
+        cur = torch.cuda.current_stream()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        cur.wait_event(ev)
+        for t in (x_t_latent, depth_latent):
+            if t.is_cuda:
+                t.record_stream(cur)
+        x_0 = self.predict_x0_batch(x_t_latent.unsqueeze(2), depth_latent.unsqueeze(2))
+        x_output = self.decode_image(x_0[:, :, 0]).detach().clone()
+        self.prev_image_result = x_output
+        end.record()
+        cur.synchronize()                                     # (this stream only: the next frame's side-stream work keeps running)
+        inference_time = start.elapsed_time(end) / 1000
+        self.inference_time_ema = 0.9 * self.inference_time_ema + 0.1 * inference_time
+        self.inference_time_list.append(inference_time)
+        return x_output
+
     def predict_x0_batch(self, x_t_latent, depth_latent, noise: Optional[torch.Tensor] = None):
         """reference :573-623 (stream-batch shift register). `noise` lets tests inject the re-noising tensor."""
         n = self.denoising_steps_num

@@ -287,3 +287,60 @@ def test_whole_pipeline_on_hip_backends():
     for i, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), f"frame {i}: host-driven step and device step differ"
     assert det.plan_summary().keys() >= {(1, 384, 384), (cfg.sink_size, 384, 384)}      # per-frame call and the warm-up batch
+
+
+def test_pipelined_push_pop_equals_call():
+    """Opt-in frame pipelining (`enable_frame_pipelining`, push / pop): the work in front of the UNet runs on a second HIP stream,
+    one frame ahead of the UNet step and decode on the caller's stream.  Same frames, same seeds: the outputs of `pop()` are
+    bit-identical to those of `__call__` (re-noising on, so the order of the random draws matters too), whatever the
+    push-ahead depth."""
+    from types import SimpleNamespace
+
+    from live2diff_amd.config import tiny_config
+    from live2diff_amd.midas_hip import HipMidas, random_midas_state_dict
+    from live2diff_amd.pipeline_stream_animation_depth import StreamAnimateDiffusionDepth
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.vae_hip import HipTinyVAE, random_taesd_state_dict
+    from live2diff_amd.weights import random_state_dict
+    cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    H = W = 128
+    sd = {k: v.to(DEV) for k, v in random_state_dict(cfg, dtype=torch.float16).items()}
+    vae = HipTinyVAE(random_taesd_state_dict(), device=DEV)
+    det = HipMidas(random_midas_state_dict(), device=DEV)
+    g = torch.Generator().manual_seed(9)
+    warm = [torch.rand(3, H, W, generator=g) for _ in range(cfg.sink_size)]
+    frames = [torch.rand(1, 3, H, W, generator=g).to(DEV) for _ in range(7)]
+    emb = torch.randn(1, 77, 64, generator=g)
+
+    def build():
+        torch.manual_seed(0)
+        pipe = SimpleNamespace(device=torch.device(DEV), vae_scale_factor=8, unet=HipStreamingUNet(sd, cfg, H // 8, W // 8, 2), vae=vae,
+                               depth_model=det, scheduler=None)
+        s = StreamAnimateDiffusionDepth(pipe, num_inference_steps=50, t_index_list=[30, 40], width=W, height=H, do_add_noise=True,
+                                        warmup_frames=cfg.sink_size, window_size=cfg.window_size)
+        s.image_processor.assume_unit_range = True
+        s.prepare_cache(H, W, 2)
+        s.prepare(warm, prompt_embeds=emb, seed=3)
+        s.enable_device_step(seed=5)
+        return s
+
+    s = build()
+    want = [s(f).clone() for f in frames]
+    assert all(torch.isfinite(r).all() for r in want) and not torch.equal(want[1], want[2])
+    for ahead in (1, 2):
+        s = build()
+        with pytest.raises(ValueError):
+            StreamAnimateDiffusionDepth.enable_frame_pipelining(SimpleNamespace(_device_step=None))
+        s.enable_frame_pipelining()
+        got = []
+        for i in range(min(ahead, len(frames))):
+            s.push(frames[i])
+        for i in range(len(frames)):
+            if i + ahead < len(frames):
+                s.push(frames[i + ahead])
+            got.append(s.pop().clone())
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), f"push-ahead {ahead}, frame {i}: pipelined output differs from __call__ ({rel(a, b):.3e})"
+    with pytest.raises(RuntimeError):
+        s.pop()
