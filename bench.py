@@ -603,7 +603,10 @@ def main():
         if name in MFMA_KERNELS:
             ach = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12
             result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc}
+                                  "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                                  "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
+                                  "note": "dominant kernel family by time; the figure comparable with the single igemm family of rounds 1-2 "
+                                          "is roofline_gemm_kernels (igemm + rowgemm + pconv)"}
         else:
             ach = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9
             result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
