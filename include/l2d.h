@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 3
+#define L2D_ABI_VERSION 4
 
 enum {
     L2D_OK = 0,
@@ -195,12 +195,13 @@ enum {
     L2D_OP_EW = 22,
     L2D_OP_ROWGEMM = 23,
     L2D_OP_PCONV = 24,
+    L2D_OP_WSGEMM = 25,
 };
 
 typedef struct l2d_op {
     int32_t kind;
     int32_t tag;          /* free for the host (plan index / layer id); echoed in error messages */
-    void *p[12];
+    void *p[16];
     int32_t i[32];
     int64_t l[4];
     float f[4];

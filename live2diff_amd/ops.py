@@ -197,6 +197,8 @@ def gn_target(op, acc_ptr: int, **kw) -> bool:
         return rowgemm_gn_target(op, acc_ptr, **kw)
     if op.kind == _lib.OP_PCONV:
         return pconv_gn_target(op, acc_ptr, **kw)
+    if op.kind == _lib.OP_WSGEMM:
+        return wsgemm_gn_target(op, acc_ptr, **kw)
     return False
 
 
@@ -351,6 +353,204 @@ def rowgemm(x, w, out, *, M, K, Nout, ldx, ldo, bias=None, res=None, ldr=0, epi=
     op.l[0] = int(st)
     op.f[0] = float(eps)
     return op, (x, w, bias, res, out, out_t)
+
+
+# ----------------------------------------------------------------------------- weight-streaming GEMM (csrc/wsgemm.hip)
+WS_BM = 128
+
+
+def pack_fragments(w2d: torch.Tensor) -> torch.Tensor:
+    """[Nout, K] (Nout % 32 == 0, K % 16 == 0) -> MFMA-fragment order: flat index (((t * S + s) * 64 + lane) * 8 + e) holds
+    W[32 t + lane % 32][16 s + 8 (lane // 32) + e] (the A operand of v_mfma_f32_32x32x16_f16 is one contiguous 1 KB block)."""
+    n, k = w2d.shape
+    assert n % 32 == 0 and k % 16 == 0, (n, k)
+    return w2d.to(torch.float16).view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def pack_wsgemm(w: torch.Tensor, bias: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                beta: Optional[torch.Tensor] = None, geglu: bool = False):
+    """Linear layer [Nout, K] (K % 64 == 0, any K) for wsgemm.hip -> (fragment-packed fp16 weights, fp32 bias or None, fp32 column
+    sums or None).  With `gamma` / `beta` (the LayerNorm in front of the layer) the affine map is folded in (W' = W diag(gamma),
+    b' = b + W beta) and `colsum[n] = sum_k fp16(W'[n][k])` is returned for the kernel's accumulator-side normalisation
+    out = rstd (x W'^T - mean colsum) + b' -- the sums are taken over the ROUNDED weights, i.e. over exactly what the matrix
+    cores multiply.  `geglu`: rows re-ordered by rowgemm_geglu_perm (bias and sums likewise)."""
+    w = w.reshape(w.shape[0], -1).float()
+    n, k = w.shape
+    assert n % 32 == 0 and k % 64 == 0, (n, k)
+    b = None if bias is None else bias.float().clone()
+    if gamma is not None:
+        if beta is not None:
+            shift = w @ beta.float()
+            b = shift if b is None else b + shift
+        w = w * gamma.float()[None, :]
+    if geglu:
+        perm = rowgemm_geglu_perm(n // 2, w.device)
+        w = w[perm]
+        b = None if b is None else b[perm]
+    w16 = w.to(torch.float16)
+    cs = w16.float().sum(1).contiguous() if gamma is not None else None
+    return pack_fragments(w16), (None if b is None else b.contiguous()), cs
+
+
+def pack_wsgemm_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] (Cout % 32 == 0) -> fragment-packed weights with k = tap * CinP + ci (CinP = round_up(Cin, 64))."""
+    return pack_fragments(pack_conv3x3(w))
+
+
+def wsgemm_ok(M: int, Nout: int, C1: int, C2: int = 0, T: int = 0) -> bool:
+    """Shapes wsgemm.hip takes: 32-row weight tiles, 64-channel chunks per input, samples made of whole 32-token MFMA tiles."""
+    return Nout % 32 == 0 and Nout >= 32 and C1 % 64 == 0 and C1 > 0 and C2 % 64 == 0 and (T <= 0 or T % 32 == 0) and M < (1 << 22)
+
+
+def _ws_lds(NW, NT, epi, ntr, gn):
+    BNp = NW * NT * 32
+    BNo = BNp // 2 if epi == 1 else BNp
+    ring = 4 * WS_BM * 64 * 2
+    ep = WS_BM * (BNo + 8) * 2 + ((64 * NW * 32 + BNo * 4) if gn else 0)
+    if ntr:
+        ep = max(ep, BNp * (WS_BM + 8) * 2)
+    return ((max(ring, ep) + 255) // 256) * 256 + 2 * WS_BM * 4 + 64
+
+
+def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0, taps: int = 1):
+    """(NW, NT, NL, S, ntw) for a wsgemm launch: consumer waves per block, 32-row weight tiles per wave, loader waves, K slices,
+    non-temporal weight loads.  The table measured in the frame (wsgemm_tuned.json, tools/wsgemm_tune.py) when it holds the
+    shape, else a cost model: a block streams BN x Kc weights (HBM, ~25 B/clk/CU chip-wide 6.4 TB/s) and 128 x Kc activations
+    (L2), runs NT * 4 * Kc / 16 MFMAs of 32 cycles per wave; blocks run in rounds over 256 CUs; each slice beyond the first adds
+    a slab write + read of 128 x BN fp32 for the last arriver."""
+    tiles = Nout // 32
+    nm = (M + WS_BM - 1) // WS_BM
+    nch = Ktot // 64
+    force = os.environ.get("L2D_WSGEMM_FORCE")        # "NW,NT,NL,S" (tools): applied where it divides the shape
+    ntw = nm == 1
+    key = f"{taps},{M},{Ktot},{Nout},{ntr},{epi},{pro}"
+    cands = []
+    for nt in (1, 2):
+        for nw in range(1, (4 if nt == 2 else 8) + 1):
+            if tiles % (nw * nt) or (ntr // 32) % (nw * nt) or (pro == 1 and nw != 4):
+                continue
+            if _ws_lds(nw, nt, epi, ntr, True) > 163840:
+                continue
+            cands.append((nw, nt))
+    assert cands, (M, Ktot, Nout, ntr, epi, pro)
+    if force:
+        nw, nt, nl, S = (int(v) for v in force.split(","))
+        if (nw, nt) in cands and not (ntr and S > 1):
+            return nw, nt, nl, max(1, min(S, nch)), ntw
+    if key in _WS_TUNED:
+        nw, nt, nl, S = _WS_TUNED[key][:4]
+        if (nw, nt) in cands:
+            return nw, nt, nl, max(1, min(S, nch)), ntw
+    cdiv = lambda a, b: (a + b - 1) // b
+    best, best_t = None, None
+    for nw, nt in cands:
+        bn = 32 * nw * nt
+        ny = tiles // (nw * nt)
+        bpc = 2 if (nt == 1 and nw <= 4 and _ws_lds(nw, nt, epi, ntr, True) <= 81920) else 1
+        for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 18, 20, 24, 30, 32, 36, 40, 45):
+            if S > nch or (S > 1 and (ntr or nch // S < 2)):
+                continue
+            blocks = nm * ny * S
+            kc = cdiv(nch, S) * 64
+            rounds = cdiv(blocks, 256 * bpc)
+            conc = min(blocks, 256 * bpc)
+            # cycles per block: weight stream at the chip's HBM share (or L2 when another row tile already pulled the band),
+            # activations from L2 at ~25 B/clk/CU, MFMA pipe shared by the waves of a SIMD
+            hbm_share = 6.4e12 / 2.4e9 / max(1, min(conc, 256))          # B/clk for this block's weight stream
+            w_cyc = bn * kc * 2 / min(30.0, hbm_share * (nm if nm > 1 else 1))
+            x_cyc = WS_BM * kc * 2 / 25.0
+            m_cyc = nt * 4 * (kc / 16) * 32 * cdiv(nw * bpc, 4)
+            t = rounds * (max(w_cyc + x_cyc, m_cyc) + 6000)
+            if S > 1:
+                t += 2500 + S * WS_BM * bn * 4 / 40.0          # arrival + the last block's slab reads (~100 GB/s per block)
+            if best_t is None or t < best_t:
+                best, best_t = (nw, nt, 1, S, ntw), t
+    return best
+
+
+def _load_ws_tuned():
+    import json
+    path = os.path.join(os.path.dirname(__file__), "wsgemm_tuned.json")
+    if os.environ.get("L2D_WSGEMM_NO_TABLE") or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)["shapes"]
+
+
+_WS_TUNED = _load_ws_tuned()
+
+
+def wsgemm_sizes(M: int, Nout: int, NW: int, NT: int, S: int):
+    """(fp32 workspace elements, int32 counters) of a split-K wsgemm launch: one slab of 128 x BN partial sums + 256 statistics
+    floats per (channel tile, row tile, slice)."""
+    nm = (M + WS_BM - 1) // WS_BM
+    ny = (Nout // 32) // (NW * NT)
+    return nm * ny * S * (WS_BM * NW * NT * 32 + 2 * WS_BM), nm * ny
+
+
+def wsgemm(x1, w, out, *, M, Nout, C1, ldx1, ldo, x2=None, C2=0, ldx2=0, bias=None, colsum=None, rowbias=None, ldrb=0,
+           rows_per_bias=0, res=None, ldr=0, taps=1, B=1, H=1, W=1, epi=0, pro=0, eps=1e-5, T=0, out_t=None, ntr=0, ldt=0,
+           st=0, sched=None, ws=None, cnt=None, cnt_off=0, x1_off=0, out_off=0, res_off=0):
+    """Weight-streaming GEMM (csrc/wsgemm.hip): out[m][n] = epi(sum_k LN?(x)[m][k] W[n][k]) for M <~ 1k tokens; linear layers
+    (taps = 1, optional two-input channel concat, LayerNorm fold pro = 1 with `colsum`, GEGLU epi = 1, trailing `ntr` packed rows
+    stored transposed into out_t) and 3x3 stride-1 pad-1 convs (taps = 9, x = [B, H, W, C1 (+ C2)], per-sample `rowbias`).
+    `w` / `bias` / `colsum` come from pack_wsgemm / pack_wsgemm_conv3x3.  sched = (NW, NT, NL, S, ntw) or None for
+    wsgemm_schedule; S > 1 needs `ws` (wsgemm_sizes()[0] floats) and `cnt` (int32 counters, zero, wsgemm_sizes()[1] from cnt_off)."""
+    op = L2dOp()
+    op.kind = _lib.OP_WSGEMM
+    CinP = C1 + C2
+    Ktot = taps * CinP
+    assert w.dtype == torch.float16 and w.numel() == Nout * Ktot, (w.shape, Nout, Ktot)
+    if sched is None:
+        sched = wsgemm_schedule(M, Ktot, Nout, ntr, epi, pro, taps)
+    NW, NT, NL, S, ntw = sched
+    zp = zero_page(x1.device)
+    op.p[0] = _ptr(_h(x1)) + 2 * x1_off
+    op.p[1] = _ptr(x2) if x2 is not None else None
+    op.p[2] = _ptr(_h(w))
+    op.p[3], op.p[4] = _ptr(bias), _ptr(rowbias)
+    op.p[5] = (_ptr(_h(res)) + 2 * res_off) if res is not None else None
+    op.p[6] = (_ptr(_h(out)) + 2 * out_off) if out is not None else None
+    op.p[7] = _ptr(zp)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Nout
+    if pro == 1:
+        assert colsum is not None and colsum.dtype == torch.float32 and colsum.numel() == Nout
+        op.p[13] = _ptr(colsum)
+    if ntr:
+        assert out_t is not None and ntr % 32 == 0
+        op.p[8] = _ptr(_h(out_t))
+    if S > 1:
+        need_ws, need_cnt = wsgemm_sizes(M, Nout, NW, NT, S)
+        assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= need_ws, (need_ws,)
+        assert cnt is not None and cnt.dtype == torch.int32 and cnt.numel() >= cnt_off + need_cnt
+        op.p[11] = _ptr(cnt) + 4 * cnt_off
+        op.p[12] = _ptr(ws)
+    vals = {0: taps, 1: C1, 2: C2, 3: ldx1, 4: ldx2, 5: CinP, 6: B, 7: H, 8: W, 9: NW, 10: NT, 11: NL, 12: S, 13: M, 14: Nout,
+            15: ldo, 16: ldr, 17: ldrb, 18: rows_per_bias, 19: epi, 20: pro, 21: ntr // 32, 22: ldt, 23: int(bool(ntw)), 30: T}
+    for j, v in vals.items():
+        op.i[j] = int(v)
+    op.l[0] = int(st)
+    op.f[0] = float(eps)
+    return op, (x1, x2, w, bias, colsum, rowbias, res, out, out_t, zp, ws, cnt)
+
+
+def wsgemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """GroupNorm statistics of a wsgemm launch's output for a consumer GroupNorm (a 128-token tile may span samples: T % 32)."""
+    assert op.kind == _lib.OP_WSGEMM
+    NW, NT, ntr, epi, M = op.i[9], op.i[10], op.i[21], op.i[19], op.i[13]
+    bno = NW * NT * 32
+    if T % 32 or M % T or ntr or epi == 1 or G > 32 or (cpg | choff) & 1 or 64 * NW < bno // 2:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
 
 
 def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, taps: int = 1):

@@ -1,0 +1,302 @@
+"""-m gpu: the weight-streaming GEMM (csrc/wsgemm.hip, L2D_OP_WSGEMM) through the C ABI against fp32 torch references on the
+same fp16-rounded inputs: linear layers (bias / residual / two-input concat), the LayerNorm fold (accumulator-side
+normalisation), GEGLU, the transposed (V^T) part, 3x3 convolutions (padding, concat, time-embedding row bias, samples smaller
+than a tile), split-K with the fused reduction (bit-repeatable), GroupNorm statistics of the output, every block geometry.
+
+Tolerance: per-op rel-L2 <= 2e-3 (3e-3 behind the LayerNorm fold), SURVEY.md section 8c."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def check(a, b, tol=2e-3, what=""):
+    assert torch.isfinite(a.float()).all(), f"{what}: non-finite output"
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel-L2 {e:.3e} > {tol:.1e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from live2diff_amd import _lib, ops
+    print("device:", _lib.device_name())
+    return ops
+
+
+def _split_bufs(L, M, N, sched):
+    NW, NT, NL, S, ntw = sched
+    if S <= 1:
+        return {}
+    nws, ncnt = L.wsgemm_sizes(M, N, NW, NT, S)
+    return dict(ws=torch.empty(nws, dtype=torch.float32, device=DEV), cnt=torch.zeros(ncnt + 4, dtype=torch.int32, device=DEV))
+
+
+def _geoms(tiles, ntr_tiles=0, pro=0):
+    out = []
+    for nt in (1, 2):
+        for nw in range(1, (4 if nt == 2 else 8) + 1):
+            if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0 and not (pro == 1 and nw != 4):
+                out.append((nw, nt))
+    return out
+
+
+@pytest.mark.parametrize("M,K,N", [(512, 1280, 1280), (128, 1280, 1280), (512, 5120, 1280), (128, 2560, 1280), (300, 64, 96),
+                                   (77, 128, 32), (1000, 192, 256), (64, 2048, 64), (2048, 640, 640)])
+def test_wsgemm_linear_bias_residual(L, M, K, N):
+    """out = x W^T + b + r for the frame's small-token shapes and odd ones (ragged M, one chunk), default schedule"""
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3).float(), rnd(M, N, seed=4)
+    ref = (x.float() @ w.float().t() + b).half().float() + r.float()
+    wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
+    sched = L.wsgemm_schedule(M, K, N)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, ldo=N, bias=bp, res=r.to(DEV), ldr=N, sched=sched,
+                   **_split_bufs(L, M, N, sched)))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"wsgemm {M}x{K}x{N} {sched}")
+    out2 = torch.empty_like(out)                      # no bias, no residual, no split
+    L.run(L.wsgemm(x.to(DEV), wp, out2, M=M, Nout=N, C1=K, ldx1=K, ldo=N, sched=sched[:3] + (1, False)))
+    torch.cuda.synchronize()
+    check(out2, x.float() @ w.float().t(), what="no bias")
+
+
+@pytest.mark.parametrize("K", [320, 1280])
+def test_wsgemm_every_geometry(L, K):
+    """All (NW, NT) block geometries, one and two loader waves, temporal / non-temporal weight loads, K slices (incl. uneven
+    ones and slices shorter than the weight ring) give the same matrix; split-K results are bit-identical between runs."""
+    M, N = 300, 960
+    x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13).float()
+    ref = x.float() @ w.float().t() + b
+    wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
+    seen = 0
+    for nw, nt in _geoms(N // 32):
+        for nl, S, ntw in ((1, 1, False), (2, 1, True), (1, 3, True), (2, K // 64, False), (1, 2, False)):
+            sched = (nw, nt, nl, S, ntw)
+            out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+            bufs = _split_bufs(L, M, N, sched)
+            L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=N, C1=K, ldx1=K, ldo=N, bias=bp, sched=sched, **bufs))
+            torch.cuda.synchronize()
+            check(out, ref, what=f"geometry {sched}")
+            if S > 1:
+                assert int(bufs["cnt"].abs().sum()) == 0, "arrival counters must be left at zero"
+                out2 = torch.zeros_like(out)
+                L.run(L.wsgemm(x.to(DEV), wp, out2, M=M, Nout=N, C1=K, ldx1=K, ldo=N, bias=bp, sched=sched, **bufs))
+                torch.cuda.synchronize()
+                assert torch.equal(out, out2), f"split-K {sched}: runs differ"
+            seen += 1
+    assert seen >= 30
+
+
+@pytest.mark.parametrize("M,C,N", [(512, 1280, 3840), (128, 1280, 1280), (2048, 640, 1920), (100, 64, 128), (96, 256, 128)])
+def test_wsgemm_layernorm_fold(L, M, C, N):
+    """LayerNorm(x) W^T (+ b): gamma / beta folded into the packed weight / bias, the normalisation applied to the accumulator
+    (out = rstd (x W'^T - mean colsum(W')) + b'), vs F.layer_norm + linear in fp32; also with a large row mean and with K slices"""
+    for seed, mean in ((21, 0.3), (25, 6.0)):
+        x = (rnd(M, C, seed=seed).float() * 1.5 + mean).half()
+        w = rnd(N, C, seed=22, scale=C ** -0.5)
+        gm, bt = (1 + 0.2 * rnd(C, seed=23).float()).half(), (0.2 * rnd(C, seed=24).float()).half()
+        ref = F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5) @ w.float().t()
+        wp, bp, cs = L.pack_wsgemm(w.to(DEV), None, gm.to(DEV), bt.to(DEV))
+        assert bp is not None and cs is not None
+        for nw, nt in _geoms(N // 32, pro=1)[:4]:
+            for S in (1, 2):
+                if S > C // 64:
+                    continue
+                sched = (nw, nt, 1, S, False)
+                out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=N, C1=C, ldx1=C, ldo=N, bias=bp, colsum=cs, pro=1, eps=1e-5, sched=sched,
+                               **_split_bufs(L, M, N, sched)))
+                torch.cuda.synchronize()
+                check(out, ref, tol=3e-3, what=f"LN fold {M}x{C}x{N} mean {mean} {sched}")
+
+
+@pytest.mark.parametrize("M,C", [(512, 1280), (128, 1280), (2048, 640), (200, 64)])
+def test_wsgemm_geglu_with_layernorm(L, M, C):
+    """LayerNorm -> Linear(C, 8C) -> value * gelu(gate) (diffusers GEGLU, exact-erf GELU) in one launch"""
+    x = rnd(M, C, seed=41)
+    w, b = rnd(8 * C, C, seed=42, scale=C ** -0.5), rnd(8 * C, seed=43).float()
+    gm, bt = (1 + 0.2 * rnd(C, seed=44).float()).half(), (0.2 * rnd(C, seed=45).float()).half()
+    h = F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5) @ w.float().t() + b
+    ref = h[:, :4 * C] * F.gelu(h[:, 4 * C:])
+    wp, bp, cs = L.pack_wsgemm(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV), geglu=True)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    for sched in ((4, 1, 1, 1, False), (4, 2, 1, 1, True), (4, 1, 2, 1, True), (4, 2, 2, 2, False)):
+        if (8 * C // 32) % (sched[0] * sched[1]) or sched[3] > C // 64:
+            continue
+        L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp, colsum=cs, pro=1, eps=1e-5, epi=1,
+                       sched=sched, **_split_bufs(L, M, 8 * C, sched)))
+        torch.cuda.synchronize()
+        check(out, ref, tol=3e-3, what=f"LN + GEGLU {M}x{C} {sched}")
+    # GEGLU without a norm in front (pro = 0)
+    h0 = x.float() @ w.float().t() + b
+    wp0, bp0, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV), geglu=True)
+    L.run(L.wsgemm(x.to(DEV), wp0, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp0, epi=1))
+    torch.cuda.synchronize()
+    check(out, h0[:, :4 * C] * F.gelu(h0[:, 4 * C:]), what="GEGLU")
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 256, 1280), (2, 1024, 640), (3, 128, 256), (2, 384, 128)])
+def test_wsgemm_qkv_with_transposed_v(L, B, T, C):
+    """norm1 -> q | k | v in one launch: q | k as [M][2C] rows, V as V^T[sample][channel][ldvt] (what the flash kernel reads)"""
+    M, ldvt = B * T, (T + 7) // 8 * 8 + 8
+    x = rnd(M, C, seed=51)
+    w = rnd(3 * C, C, seed=52, scale=C ** -0.5)
+    gm, bt = (1 + 0.2 * rnd(C, seed=53).float()).half(), (0.2 * rnd(C, seed=54).float()).half()
+    ref = F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5) @ w.float().t()
+    wp, bp, cs = L.pack_wsgemm(w.to(DEV), None, gm.to(DEV), bt.to(DEV))
+    qk = torch.empty(M, 2 * C, dtype=torch.float16, device=DEV)
+    vt = torch.full((B, C, ldvt), 7.0, dtype=torch.float16, device=DEV)
+    geoms = [None] + [(nw, nt, 1, 1, False) for nw, nt in _geoms(3 * C // 32, C // 32, pro=1)]
+    for sched in geoms:
+        qk.zero_(); vt.fill_(7.0)
+        L.run(L.wsgemm(x.to(DEV), wp, qk, M=M, Nout=3 * C, C1=C, ldx1=C, ldo=2 * C, bias=bp, colsum=cs, pro=1, eps=1e-5, T=T, out_t=vt,
+                       ntr=C, ldt=ldvt, st=C * ldvt, sched=sched))
+        torch.cuda.synchronize()
+        check(qk, ref[:, :2 * C], tol=3e-3, what=f"q|k {sched}")
+        vref = ref[:, 2 * C:].view(B, T, C).permute(0, 2, 1)
+        check(vt[:, :, :T], vref, tol=3e-3, what=f"V^T {sched}")
+        assert (vt[:, :, T:] == 7.0).all(), "columns beyond T must not be written"
+
+
+def test_wsgemm_concat_input(L):
+    """conv_shortcut of the up path: one Linear over the channel concat of two tensors (two pointers, no torch.cat)"""
+    M, C1, C2, N = 512, 1280, 640, 1280
+    x1, x2 = rnd(M, C1, seed=61), rnd(M, C2, seed=62)
+    w, b = rnd(N, C1 + C2, seed=63, scale=(C1 + C2) ** -0.5), rnd(N, seed=64).float()
+    ref = torch.cat([x1, x2], 1).float() @ w.float().t() + b
+    wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    for sched in ((4, 1, 1, 1, False), (2, 2, 1, 3, False)):
+        L.run(L.wsgemm(x1.to(DEV), wp, out, M=M, Nout=N, C1=C1, ldx1=C1, x2=x2.to(DEV), C2=C2, ldx2=C2, ldo=N, bias=bp, sched=sched,
+                       **_split_bufs(L, M, N, sched)))
+        torch.cuda.synchronize()
+        check(out, ref, what=f"concat linear {sched}")
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,N", [(2, 8, 8, 1280, 0, 1280), (2, 16, 16, 1280, 0, 1280), (2, 8, 8, 1280, 1280, 1280), (2, 16, 16, 640, 0, 1280),
+                                           (3, 8, 12, 64, 64, 96), (1, 16, 24, 128, 0, 64), (2, 32, 32, 64, 0, 64)])
+def test_wsgemm_conv3x3(L, B, H, W, C1, C2, N):
+    """3x3 stride-1 pad-1 conv (+ bias + per-sample time-embedding bias + residual) over channels-last input, incl. the channel
+    concat of two inputs, samples smaller than the 128-token tile (8x8) and tiles that straddle samples (8x12), vs F.conv2d"""
+    M, Cin = B * H * W, C1 + C2
+    x1 = rnd(M, C1, seed=71)
+    x2 = rnd(M, C2, seed=72) if C2 else None
+    w, b = rnd(N, Cin, 3, 3, seed=73, scale=(9 * Cin) ** -0.5), rnd(N, seed=74).float()
+    temb = rnd(B, N + 32, seed=75).float()
+    r = rnd(M, N, seed=76)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    conv = F.conv2d(xin.float().view(B, H, W, Cin).permute(0, 3, 1, 2), w.float(), b, padding=1)
+    conv = conv + temb[:, 16:16 + N, None, None]
+    ref = conv.permute(0, 2, 3, 1).reshape(M, N).half().float() + r.float()
+    wp = L.pack_wsgemm_conv3x3(w.to(DEV))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    tdev = temb.to(DEV)
+    Ktot = 9 * Cin
+    scheds = [L.wsgemm_schedule(M, Ktot, N, taps=9)] + [(nw, nt, nl, S, False) for (nw, nt), nl, S in
+                                                          zip(_geoms(N // 32)[:4], (1, 2, 1, 2), (1, 5, 9, 2))]
+    for sched in scheds:
+        op, keep = L.wsgemm(x1.to(DEV), wp, out, M=M, Nout=N, C1=C1, ldx1=C1, x2=(x2.to(DEV) if C2 else None), C2=C2, ldx2=C2, ldo=N,
+                            bias=b.to(DEV), rowbias=tdev, ldrb=N + 32, rows_per_bias=H * W, res=r.to(DEV), ldr=N, taps=9, B=B, H=H, W=W,
+                            sched=sched, **_split_bufs(L, M, N, sched))
+        op.p[4] = tdev.data_ptr() + 4 * 16                   # (the plan points into the concatenated time-embedding row like this)
+        L.run((op, keep))
+        torch.cuda.synchronize()
+        check(out, ref, what=f"conv3x3 B{B} {H}x{W} C{C1}+{C2}->{N} {sched}")
+
+
+@pytest.mark.parametrize("B,T,K,C,choff2,Ccat,taps", [(2, 256, 1280, 1280, 0, 2560, 1), (2, 64, 1280, 1280, 1280, 2560, 1), (8, 64, 320, 320, 0, 640, 1),
+                                                      (2, 64, 1280, 1280, 0, 2560, 9), (2, 256, 640, 1280, 1280, 2560, 9), (3, 96, 64, 64, 64, 128, 1)])
+def test_wsgemm_groupnorm_statistics_of_the_output(L, B, T, K, C, choff2, Ccat, taps):
+    """launches accumulate sum / sum of squares of what they store for up to two consumer GroupNorms (the fixed-point protocol of
+    igemm / rowgemm), per SAMPLE also when a 128-token tile spans two samples; split-K launches do it in the reducing block."""
+    G, M = 32, B * T
+    H = 8
+    Wd = T // H
+    x, r, b = rnd(M, K, seed=81), rnd(M, C, seed=84), rnd(C, seed=83).float()
+    if taps == 9:
+        w = rnd(C, K, 3, 3, seed=82, scale=(9 * K) ** -0.5)
+        wp, bp = L.pack_wsgemm_conv3x3(w.to(DEV)), b.to(DEV)
+        full = F.conv2d(x.float().view(B, H, Wd, K).permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, C)
+    else:
+        w = rnd(C, K, seed=82, scale=K ** -0.5)
+        wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
+        full = x.float() @ w.float().t() + b
+    ref = full.half().float() + r.float()
+    out = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    acc = torch.zeros(2, B, G, 2, dtype=torch.int64, device=DEV)
+    cpg1, cpg2 = C // G, Ccat // G
+    for sched in ((4, 1, 1, 1, False), (2, 1, 1, 1, False), (2, 1, 2, 4, False)) + (((4, 2, 1, 2, False),) if C % 256 == 0 else ()):
+        if (C // 32) % (sched[0] * sched[1]) or sched[3] > taps * K // 64:
+            continue
+        accs = []
+        for rep in range(2):
+            acc.zero_()
+            op, keep = L.wsgemm(x.to(DEV), wp, out, M=M, Nout=C, C1=K, ldx1=K, ldo=C, bias=bp, res=r.to(DEV), ldr=C, taps=taps, B=B, H=H,
+                                W=Wd, T=T, sched=sched, **_split_bufs(L, M, C, sched))
+            assert L.gn_target(op, acc[0].data_ptr(), T=T, G=G, cpg=cpg1, choff=0)
+            assert L.gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=choff2)
+            assert not L.gn_target(op, acc[1].data_ptr(), T=T, G=G, cpg=cpg2, choff=0)
+            L.run((op, keep + (acc,)))
+            torch.cuda.synchronize()
+            accs.append(acc.clone())
+        assert torch.equal(accs[0], accs[1]), f"{sched}: statistics differ between runs"
+        check(out, ref, what=f"output {sched}")
+        o = out.float().cpu().view(B, T, C)
+        a0 = accs[0].cpu().double()
+        s1, s2 = o.double().view(B, T, G, cpg1).sum((1, 3)), (o.double() ** 2).view(B, T, G, cpg1).sum((1, 3))
+        assert (a0[0, :, :, 0] / 2 ** 20 - s1).abs().max() <= 1e-3 * max(1.0, s1.abs().max().item()), sched
+        assert (a0[0, :, :, 1] / 2 ** 12 - s2).abs().max() <= 1e-3 * s2.abs().max().item(), sched
+        fullc = torch.zeros(B, T, Ccat, dtype=torch.float64)
+        fullc[:, :, choff2:choff2 + C] = o.double()
+        t1, t2 = fullc.view(B, T, G, cpg2).sum((1, 3)), (fullc ** 2).view(B, T, G, cpg2).sum((1, 3))
+        assert (a0[1, :, :, 0] / 2 ** 20 - t1).abs().max() <= 1e-3 * max(1.0, t1.abs().max().item()), sched
+        assert (a0[1, :, :, 1] / 2 ** 12 - t2).abs().max() <= 1e-3 * t2.abs().max().item(), sched
+
+
+def test_wsgemm_matches_rowgemm_and_igemm_on_frame_shapes(L):
+    """the same layer through the three GEMM kernels: results agree to fp16 rounding (different accumulation orders)"""
+    M, K, N = 512, 1280, 1280
+    x, w, b, r = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=K ** -0.5), rnd(N, seed=93).float(), rnd(M, N, seed=94)
+    wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
+    o_ws = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    L.run(L.wsgemm(x.to(DEV), wp, o_ws, M=M, Nout=N, C1=K, ldx1=K, ldo=N, bias=bp, res=r.to(DEV), ldr=N, sched=(4, 1, 1, 1, False)))
+    wr, br = L.pack_rowgemm(w.to(DEV), b.to(DEV))
+    o_rg = torch.empty_like(o_ws)
+    L.run(L.rowgemm(x.to(DEV), wr, o_rg, M=M, K=K, Nout=N, ldx=K, ldo=N, bias=br, res=r.to(DEV), ldr=N))
+    wi = L.pack_linear(w.to(DEV))
+    o_ig = torch.empty_like(o_ws)
+    L.run(L.igemm(x.to(DEV), wi, o_ig, M=M, Nout=N, C1=K, ldx1=K, CinP=K, ldo=N, bias=b.to(DEV), res=r.to(DEV), ldr=N, tile=2, variant=1))
+    torch.cuda.synchronize()
+    assert torch.equal(wp, wr), "wsgemm and rowgemm share the fragment packing"
+    check(o_ws, o_rg.float(), tol=5e-4, what="wsgemm vs rowgemm")
+    check(o_ws, o_ig.float(), tol=5e-4, what="wsgemm vs igemm")
+
+
+def test_wsgemm_rejects_bad_arguments(L):
+    from live2diff_amd import _lib
+    x, w = rnd(128, 64).to(DEV), rnd(64, 64).to(DEV)
+    wp, _, _ = L.pack_wsgemm(w)
+    out = torch.empty(128, 64, dtype=torch.float16, device=DEV)
+    with pytest.raises(_lib.L2DError):
+        L.run(L.wsgemm(x, wp, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(3, 1, 1, 1, False)))      # 2 tiles over 3 waves
+    with pytest.raises(_lib.L2DError):
+        L.run(L.wsgemm(x, wp, out, M=128, Nout=64, C1=64, ldx1=64, ldo=60))                                  # ldo % 8
+    with pytest.raises(_lib.L2DError):
+        op, keep = L.wsgemm(x, wp, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(2, 1, 1, 1, False))
+        op.i[12] = 2                                                                                         # split-K without workspace
+        L.run((op, keep))
+    with pytest.raises(_lib.L2DError):
+        op, keep = L.wsgemm(x, wp, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(2, 1, 1, 1, False))
+        op.i[20] = 1                                                                                         # LayerNorm fold needs colsum and 4 waves
+        L.run((op, keep))

@@ -97,8 +97,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib.l2d_abi_version() == _lib.ABI_VERSION == 3
-    assert ctypes.sizeof(_lib.L2dOp) == 280          # ABI v2: 12 pointers + 32 ints + 4 int64 + 4 floats (+ kind, tag)
+    assert _lib.lib.l2d_abi_version() == _lib.ABI_VERSION == 4
+    assert ctypes.sizeof(_lib.L2dOp) == 312          # ABI v4: 16 pointers + 32 ints + 4 int64 + 4 floats (+ kind, tag)
     # error path without a device: refused loudly, no fallback
     ops = (_lib.L2dOp * 1)()
     ops[0].kind = 99

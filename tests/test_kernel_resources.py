@@ -31,6 +31,7 @@ def kernels(tmp_path_factory):
                          for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size")}
             out[name]["agpr_count"] = int(re.match(r"\s*(\d+)", blk).group(1))
     assert len(out) > 100, f"only {len(out)} kernels found in the code objects"
+    out["__code_objects__"] = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "gfx950" in f]
     return out
 
 
@@ -43,7 +44,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
     generic_k = re.compile(r"rowgemm_kernelILi\dELi\dELi\d+ELi0ELi\d+E")
     bad = {}
     for n, k in kernels.items():
-        if n in legacy or not (k["vgpr_spill_count"] or k["private_segment_fixed_size"]):
+        if n.startswith("__") or n in legacy or not (k["vgpr_spill_count"] or k["private_segment_fixed_size"]):
             continue
         if generic_k.search(n) and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] <= 128:
             continue
@@ -53,7 +54,7 @@ def test_no_kernel_spills_or_uses_scratch(kernels):
 
 def test_occupancy_budgets(kernels):
     def pick(pat):
-        r = {n: k for n, k in kernels.items() if re.search(pat, n)}
+        r = {n: k for n, k in kernels.items() if not n.startswith("__") and re.search(pat, n)}
         assert r, pat
         return r
     # 128x128 tile with a BK = 32 ring: three (NS = 3, 4, 6) or four (NS = 2) blocks of four waves per CU -> <= 168 / 128 registers
@@ -84,3 +85,89 @@ def test_occupancy_budgets(kernels):
     # token-resident GEMM, compile-time K: the geometries with up to 8 waves per block rely on <= 256 registers, no spills
     for n, k in pick(r"rowgemm_kernelILi\dELi\dELi\d+ELi(20|40|80)E").items():
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)
+    # weight-streaming GEMM: 5-6 waves per block share a CU two per SIMD (<= 256 registers), the 8-consumer form three (<= 168)
+    ws = pick(r"wsgemm_kernel")
+    assert len(ws) == 20, sorted(ws)
+    for n, k in ws.items():
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)
+        assert k["vgpr_count"] + k["agpr_count"] <= (168 if "Li10EEv" in n else 256), (n, k)
+
+
+def _regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def test_wsgemm_weight_ring_registers_are_untouched_in_flight(kernels):
+    """wsgemm.hip issues its weight-fragment loads and their counted waits as inline asm (the compiler's own waitcnt insertion
+    would drain them at every loop back-edge).  The compiler therefore believes a ring register holds its value from the moment
+    the load is ISSUED; this is only sound if nothing reads or writes such a register while its load is in flight (no copies at
+    loop back-edges, no spills, no early reuse).  Checked on the shipped ISA by walking the control-flow graph of the consumer
+    code of every wsgemm kernel (both outcomes of every conditional branch, states memoised so loops close) with the hardware's
+    in-order VMEM return rule: a fragment load enters a FIFO, `s_waitcnt vmcnt(N)` retires all but the youngest N; no instruction
+    may touch a register of a load that is still in the FIFO -- in particular every MFMA must find its A operand landed."""
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    n_checked = 0
+    for co in kernels["__code_objects__"]:
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        if "wsgemm_kernel" not in dis:
+            continue
+        for fn in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+            head = fn.split("\n", 1)[0]
+            if "wsgemm_kernel" not in head:
+                continue
+            ins, addr = [], []
+            for line in fn.split("\n")[1:]:
+                m = re.match(r"\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+                if m:
+                    ins.append(m.group(1))
+                    addr.append(int(m.group(2), 16))
+            index = {a: i for i, a in enumerate(addr)}
+            is_frag = lambda t: re.match(r"global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[", t) is not None
+            start = next(i for i, t in enumerate(ins) if is_frag(t))
+            work, seen, max_depth, n_steps = [(start, ())], set(), 0, 0
+            while work:
+                pc, fifo = work.pop()
+                while True:
+                    key = (pc, fifo)
+                    if key in seen or pc >= len(ins):
+                        break
+                    seen.add(key)
+                    n_steps += 1
+                    assert n_steps < 2_000_000, head
+                    t = ins[pc]
+                    toks = [x.rstrip(",") for x in t.split()[1:]]
+                    if t.startswith("s_endpgm"):
+                        break
+                    if is_frag(t):
+                        dst = frozenset(_regs(toks[0]))
+                        inflight = set().union(*fifo) if fifo else set()
+                        assert not (dst & inflight) and not (_regs(toks[1]) & inflight), f"{head}: `{t}` while in flight"
+                        fifo = fifo + (dst,)
+                        max_depth = max(max_depth, len(fifo))
+                        pc += 1
+                        continue
+                    m = re.search(r"vmcnt\((\d+)\)", t)
+                    if t.startswith("s_waitcnt") and m:
+                        fifo = fifo[max(0, len(fifo) - int(m.group(1))):]
+                        pc += 1
+                        continue
+                    if t.startswith("s_branch") or t.startswith("s_cbranch"):
+                        imm = int(toks[0])
+                        tgt = index[addr[pc] + 4 + 4 * (imm - 65536 if imm >= 32768 else imm)]
+                        if t.startswith("s_cbranch"):
+                            work.append((pc + 1, fifo))
+                        pc = tgt
+                        continue
+                    if fifo:
+                        assert not re.match(r"(global_|buffer_|flat_|scratch_)", t), f"{head}: `{t}`: foreign VMEM op inside the counted region"
+                        touched = set().union(*[_regs(x) for x in toks]) if toks else set()
+                        inflight = set().union(*fifo)
+                        assert not (touched & inflight), f"{head}: `{t}` touches a fragment register whose load is still in flight"
+                    pc += 1
+            assert max_depth in (8, 16), (head, max_depth)
+            n_checked += 1
+    assert n_checked == 20, n_checked
