@@ -271,6 +271,76 @@ extern "C" int l2d_read_bench(const void *src, void *sink, int64_t bytes, int un
 }
 
 #ifdef L2D_PROBES
+// Per-CU ingest probe (analysis builds only, tools/ingest_probe.py): `grid` blocks (one per CU while grid <= 256) of `waves`
+// waves; every wave keeps U wave-instructions of 1 KB (16 B per lane) in flight, `iters` batches.  mode 0: every wave streams its
+// private region (cold: HBM), mode 1: every wave walks the SAME `region` bytes (L2 / Infinity-Cache hits), mode 2 / 3: the same
+// two patterns through global_load_lds (LDS-DMA, no VGPR staging).  Answers: what can ONE CU pull from HBM / from L2, with how
+// many requests in flight, and how does that scale with the number of active CUs.
+template <int U, int MODE>
+__global__ __launch_bounds__(1024) void ingest_kernel(const char *src, unsigned *sink, long long region, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const long long gw = (long long)blockIdx.x * nw + wave;
+    const bool priv = (MODE == 0 || MODE == 2);
+    const char *base = priv ? src + gw * region : src + (gw * 4096) % region;
+    const long long wrap = region - U * 1024;
+    unsigned acc = 0;
+    long long off = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE >= 2) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *)(base + off + u * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(ring + (wave * U + u) * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4 *>(base + off + u * 1024 + lane * 16);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc ^= __float_as_uint(v[u][0]) ^ __float_as_uint(v[u][3]);
+        }
+        off += U * 1024;
+        if (off > wrap) off = 0;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+extern "C" int l2d_ingest_bench(const void *src, void *sink, int64_t region, int mode, int grid, int waves, int inflight, int iters,
+                                void *stream, float *gbps_out) {
+    if (!src || !sink || !gbps_out || grid <= 0 || waves <= 0 || waves > 16 || iters <= 0 || region < inflight * 1024) {
+        l2d_set_error("ingest_bench: invalid arguments");
+        return L2D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = mode >= 2 ? (size_t)waves * inflight * 1024 : 0;
+    auto launch = [&]() {
+#define ING(U, M) hipLaunchKernelGGL((ingest_kernel<U, M>), dim3(grid), dim3(64 * waves), lds, s, (const char *)src, (unsigned *)sink, (long long)region, iters)
+#define INGU(M) switch (inflight) { case 2: ING(2, M); break; case 4: ING(4, M); break; case 8: ING(8, M); break; case 16: ING(16, M); break; default: ING(32, M); break; }
+        switch (mode) { case 0: INGU(0) break; case 1: INGU(1) break; case 2: INGU(2) break; default: INGU(3) break; }
+#undef INGU
+#undef ING
+    };
+    if (lds > 65536) {
+        l2d_set_error("ingest_bench: LDS-DMA modes take waves * inflight <= 64");
+        return L2D_EINVAL;
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    launch();
+    hipEventRecord(e0, s);
+    launch();
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *gbps_out = (float)((double)grid * waves * inflight * 1024.0 * iters / (ms * 1e-3) / 1e9);
+    return l2d_check_launch("ingest_bench", 0);
+}
+
 // Access-pattern probe for the KV-cache stream (analysis builds only, tools/kv_pattern_probe.py).  One 320-thread block per CU
 // streams its private slice of `src` HBM -> LDS with the ring discipline of tattn_ring.hip (NS stages of R DMA wave-instructions,
 // counted vmcnt waits, one barrier per stage) and NO arithmetic.  `pattern` picks what a stage fetches from a group of 8 pixels

@@ -59,7 +59,18 @@ struct WsArgs {
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
     int stat_off;                  // byte offset of the row-statistics block in LDS
     float eps;
+#ifdef L2D_PROBES
+    unsigned long long *probe;     // analysis builds: 64 s_memtime stamps per block (loader 0: 0..31, consumer 0: 32..63), tools/wsgemm_stamps.py
+#endif
 };
+
+#ifdef L2D_PROBES
+static unsigned long long *g_wsgemm_probe = nullptr;
+extern "C" void l2d_wsgemm_set_probe(void *p) { g_wsgemm_probe = (unsigned long long *)p; }
+#define WS_STAMP(i) do { if (a.probe && lane == 0) a.probe[(unsigned long long)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
 
 // q = m / d for 0 <= m < 2^22 with a host-computed float reciprocal (one estimate, one correction step)
 __device__ __forceinline__ int ws_div(int m, int d, float inv, int &rem) {
@@ -86,6 +97,17 @@ template <int N>
 __device__ __forceinline__ void ws_gwait(h16x8 &a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void ws_gwait(h16x8 &a, h16x8 &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+// The activation-fragment reads (LDS) are asm for the same reason: behind inline asm hipcc waits lgkmcnt(0) before every use of a
+// double-buffered fragment, i.e. for the reads it has just issued for the NEXT step.  LDS returns in order: with at most N
+// younger reads outstanding the four fragments of this step have landed.
+template <int OFF>
+__device__ __forceinline__ void ws_lread(h16x8 &dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+template <int N>
+__device__ __forceinline__ void ws_lwait(h16x8 &a, h16x8 &b, h16x8 &c, h16x8 &d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void ws_lwait1(h16x8 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 // end of the K slice: everything this wave requested has landed.  ALL ring registers are operands: the last ring of a slice
 // holds clamped duplicate requests that nothing consumes, and a register the compiler considers dead would be handed to other
 // values while the hardware can still write it.
@@ -94,9 +116,9 @@ __device__ __forceinline__ void ws_gdrain8(h16x8 &a, h16x8 &b, h16x8 &c, h16x8 &
 }
 
 // NT: 32-row weight tiles per consumer wave; RDS: depth of the weight register ring in stages (4 k steps each); NL: loader waves;
-// NTW: non-temporal weight loads; PRO: LayerNorm fold (row statistics summed in the loop; exactly 4 consumer waves);
+// NTW: non-temporal weight loads;
 // MAXW: launch bound in waves (sets the register budget: <= 6 waves -> 256 VGPRs, 10 -> 168)
-template <int NT, int RDS, int NL, bool NTW, bool PRO, int MAXW>
+template <int NT, int RDS, int NL, bool NTW, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
     constexpr int BM = 128, MT = 4, NS = 4;
     constexpr int STG = BM * 64;                               // halfs per ring stage (128 tokens x 64 channels)
@@ -122,6 +144,9 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
     const int n = a.cps + (z < a.crem ? 1 : 0);
 
     float *stat = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + a.stat_off);      // [128][2]
+    // epilogue parameters of this block's columns, DMA'd into LDS by loader wave 0 before anything else (bias | column sums | up to
+    // four time-embedding rows): read as cold global loads at the START of the epilogue they were ~1 us of exposed latency per block
+    float *par = stat + 2 * BM + 16;
 
     f32x16 acc[NT][MT];
 #pragma unroll
@@ -132,6 +157,31 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][mt][e] = 0.f;
     const int l32 = lane & 31, lh = lane >> 5;
 
+    // row phase geometry of the epilogue (whole output rows, 16 bytes per lane): thread -> (row rr + k RPP, 8-channel chunk cc),
+    // k < 8 NT.  The residual rows are requested EARLY: with one weight tile per wave (NT = 1: registers to spare) in front of the
+    // weight ring -- they are older than every fragment in the in-order VMEM queue, so the first counted wait of the k loop covers
+    // them and they cost no round trip of their own -- with two tiles right behind the k loop, under the tile staging.
+    const int BNp = NW * NT * 32;                              // packed weight rows of this block
+    const int BNo = a.epi == 1 ? BNp >> 1 : BNp;               // output columns
+    const int nb_p = y * BNp, nb_o = y * BNo;
+    const bool cons = wave < NW;
+    const int CPR = BNo >> 3, RPP = nthr / CPR;
+    const int rr = tid / CPR, cc = tid - rr * CPR;
+    const bool on = cons && rr < RPP;
+    constexpr bool RES_EARLY = NT == 1 && MAXW <= 6;            // (the other forms run at their register budget)
+    constexpr int EITMAX = 8 * NT, PF = RES_EARLY ? 8 : (NT == 1 ? 2 : 1);
+    h16x8 resp[PF];
+    auto request_residual = [&]() {
+        if (a.res && on && y < a.ytr) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                int row = rr + k * RPP;
+                row = (row < BM && m0 + row < a.M) ? row : 0;      // (clamped: an unconditional load)
+                resp[k] = l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + cc * 8);
+            }
+        }
+    };
+
     if (wave >= NW) {
         // ------------------------------------------------------------------------------------------ loader wave(s)
         // DMA instruction i (0..15) of a stage moves tokens 8 i .. 8 i + 7, lane -> (token 8 i + lane / 8, LDS slot position
@@ -139,9 +189,32 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
         // which makes the consumers' ds_read_b128 fragment reads (32 consecutive tokens, one slot) conflict-free.
         const int l = wave - NW;
         const int sub = lane >> 3, qpos = lane & 7;
-        int pix[IPL], yx[IPL], qo[IPL];
+        if (l == 0) WS_STAMP(0);                                // loader entry
+        if (l == 0) {
+            const int bnp = NW * NT * 32, nbp = y * bnp;
+            for (int c = lane; c < ((bnp + 63) & ~63); c += 64) {   // (whole wave-instructions; lanes beyond the block's columns re-read its last one)
+                const int cl = c < bnp ? c : bnp - 1;
+                const int cbase = c - lane;                     // wave-uniform LDS position of this instruction
+                if (a.bias) __builtin_amdgcn_global_load_lds(L2D_GPTR(a.bias + nbp + cl), L2D_LPTR(par + cbase), 4, 0, 0);
+                if (a.pro == 1) __builtin_amdgcn_global_load_lds(L2D_GPTR(a.colsum + nbp + cl), L2D_LPTR(par + 256 + cbase), 4, 0, 0);
+                if (a.rowbias) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        int mm = m0 + 32 * mt;
+                        if (mm >= a.M) mm = a.M - 1;
+                        const float *rbp = a.rowbias + (long long)(mm / a.rows_per_bias) * a.ldrb;
+                        __builtin_amdgcn_global_load_lds(L2D_GPTR(rbp + nbp + cl), L2D_LPTR(par + 512 + mt * 256 + cbase), 4, 0, 0);
+                    }
+                }
+            }
+        }
+        // per DMA instruction of this lane: byte offset of its token's pixel row in x1 / x2 (+ its 16-byte slot), and for 3x3
+        // convs the 9-bit mask of the taps whose neighbour pixel lies inside the image (bit 4 = the pixel itself; rows beyond M: 0).
+        // The per-stage work is then: one wave-uniform offset (channel chunk + neighbour displacement), per instruction one mask
+        // test, one select against the zero page and one 64-bit add -- the issue loop of this wave is what paces a stage.
+        int off1[IPL], off2[IPL], vm[IPL];
         {
-            const int i0 = l, m = m0 + 8 * i0 + sub;
+            const int m = m0 + 8 * l + sub;
             int yy = 0, xx = 0;
             if (a.taps == 9) {
                 int p, b = ws_div(m, a.T, a.invT, p);
@@ -151,52 +224,125 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
 #pragma unroll
             for (int j = 0; j < IPL; ++j) {
                 const int i = l + j * NL, mm = m0 + 8 * i + sub;
-                pix[j] = mm < a.M ? mm : -1;
-                yx[j] = (yy << 16) | xx;
-                qo[j] = (((((i & 1) << 2) | (sub >> 1)) ^ qpos)) << 3;
-                if (a.taps == 9) {                              // next token of this lane: 8 NL pixels further (W >= 8: at most two row wraps)
-                    xx += 8 * NL;
+                const int q8 = (((((i & 1) << 2) | (sub >> 1)) ^ qpos)) << 3;
+                off1[j] = (mm * a.ldx1 + q8) * 2;
+                off2[j] = (mm * a.ldx2 + q8) * 2;
+                int msk = 1 << 4;
+                if (a.taps == 9) {
+                    const int xm = (xx > 0 ? 1 : 0) | 2 | (xx < a.W - 1 ? 4 : 0);
+                    msk = (yy > 0 ? xm : 0) | (xm << 3) | (yy < a.H - 1 ? xm << 6 : 0);
+                    xx += 8 * NL;                               // next token of this lane: 8 NL pixels further (W >= 8: at most two row wraps)
                     if (xx >= a.W) { xx -= a.W; ++yy; }
                     if (xx >= a.W) { xx -= a.W; ++yy; }
                     if (yy >= a.H) yy -= a.H;
                 }
+                vm[j] = mm < a.M ? msk : 0;
             }
         }
+        // Stages come in SEGMENTS: runs of consecutive channel chunks of one tap and one input tensor.  Inside a segment every
+        // source address advances by 128 bytes per stage, so the issue loop is one 64-bit add + one DMA per instruction; padding /
+        // ragged rows walk through the zero region (p7: at least 2 CinP + 256 zero bytes) the same way.  A segment starts with one
+        // mask test + select + add per instruction.
         int tap = 4, cc = c0;                                   // (linear layers: the centre tap, dy = dx = 0)
         if (a.taps == 9) { tap = c0 / a.ncpt; cc = c0 - tap * a.ncpt; }
-        auto issue_stage = [&](int slot) {
+        const char *zp = reinterpret_cast<const char *>(a.zero);
+        const char *cur[IPL];
+        int seg_left = 0;
+        const int nc1 = a.C1 >> 6;
+        auto begin_segment = [&]() {
             const int t3 = (tap * 11) >> 5;                     // tap / 3 for tap < 9
-            const int dy = t3 - 1, dx = tap - 3 * t3 - 1;
-            const int cb = cc * 64;
-            const bool first = cb < a.C1;
-            const h16 *xb = first ? a.x1 : a.x2;
-            const int ld = first ? a.ldx1 : a.ldx2, ch = first ? cb : cb - a.C1;
-            const int delta = dy * a.W + dx;
+            const int delta = (t3 - 1) * a.W + (tap - 3 * t3 - 1);      // neighbour displacement in pixels (0 for linear layers)
+            const bool first = cc < nc1;
+            const char *xb = reinterpret_cast<const char *>(first ? a.x1 : a.x2) +
+                             ((long long)delta * (first ? a.ldx1 : a.ldx2) + (first ? cc : cc - nc1) * 64) * 2;     // wave-uniform
+            const int bit = 1 << tap;
+#pragma unroll
+            for (int j = 0; j < IPL; ++j) cur[j] = (vm[j] & bit) ? xb + (first ? off1[j] : off2[j]) : zp;
+            seg_left = first ? nc1 - cc : a.ncpt - cc;
+        };
+        auto issue_stage = [&](int slot) {
+            if (seg_left == 0) begin_segment();
             h16 *dst = smem + slot * STG;
 #pragma unroll
             for (int j = 0; j < IPL; ++j) {
                 const int i = l + j * NL;
-                const int yy = (yx[j] >> 16) + dy, xx = (yx[j] & 0xffff) + dx;
-                const bool ok = pix[j] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-                const h16 *src = ok ? xb + (long long)(pix[j] + delta) * ld + ch + qo[j] : a.zero;
-                __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(L2D_GPTR(cur[j]), L2D_LPTR(dst + i * 512), 16, 0, 0);
+                cur[j] += 128;
             }
+            --seg_left;
             if (++cc == a.ncpt) { cc = 0; ++tap; }
         };
+        // LayerNorm fold: the row statistics (sum x, sum x^2 over this block's K slice) are taken HERE, by the loader wave(s), from
+        // the bytes they moved: once its share of a stage has landed the wave reads it back from LDS -- lane-linear, the very
+        // 16 bytes per lane it requested -- and accumulates per DMA instruction (= per token of this lane) with v_dot2.  The
+        // consumers' loop is the same with and without the norm, and any number of consumer waves will do.
+        float sx[IPL], sq[IPL];
+#pragma unroll
+        for (int j = 0; j < IPL; ++j) { sx[j] = 0.f; sq[j] = 0.f; }
+        const bool stats = a.pro == 1;
+        auto stage_stats = [&](int slot) {
+            const unsigned src = (unsigned)(size_t)L2D_LPTR(smem) + (slot * STG + lane * 8) * 2;
+            const h16x2 ones2 = {(h16)1.0f, (h16)1.0f};
+#pragma unroll
+            for (int j0 = 0; j0 < IPL; j0 += 8) {               // batches of 8 reads: one LDS latency per batch
+                h16x8 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(src + (l + (j0 + j) * NL) * 1024));
+                ws_lwait<0>(v[0], v[1], v[2], v[3]);
+                ws_lwait<0>(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const h16x2 pr = {v[j][2 * e], v[j][2 * e + 1]};
+                        sx[j0 + j] = __builtin_amdgcn_fdot2(pr, ones2, sx[j0 + j], false);
+                        sq[j0 + j] = __builtin_amdgcn_fdot2(pr, pr, sq[j0 + j], false);
+                    }
+                }
+            }
+        };
         const int npre = n < NS - 1 ? n : NS - 1;
+        if (l == 0) WS_STAMP(1);                                // descriptors ready
         for (int s = 0; s < npre; ++s) issue_stage(s);
+        if (l == 0) WS_STAMP(2);                                // first stages requested
         int s = 0;
         for (; s + (NS - 1) < n; ++s) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPL) : "memory");     // stage s has landed (this wave's share)
+            if (l == 0 && s < 12) WS_STAMP(3 + 2 * s);          // stage s landed
             __builtin_amdgcn_s_barrier();      // ... every loader's has; the consumers are done with stage s - 1
+            if (l == 0 && s < 12) WS_STAMP(4 + 2 * s);          // barrier s passed
             issue_stage((s + NS - 1) & (NS - 1));
-        }
+            if (stats) stage_stats(s & (NS - 1));               // (this wave's own share of stage s: landed above; its slot is refilled
+        }                                                       //  by this wave's NEXT issue, behind these reads)
         for (; s < n; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0 && s < 12) WS_STAMP(3 + 2 * s);
             __builtin_amdgcn_s_barrier();
+            if (l == 0 && s < 12) WS_STAMP(4 + 2 * s);
+            if (stats) stage_stats(s & (NS - 1));
         }
+        if (stats) {
+            // the 8 lanes of a token (its 8 channel slots) are adjacent: sum them on DPP, lane qpos == 0 publishes the token's sums
+            auto dpp = [](float x, auto ctrl) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+            };
+#pragma unroll
+            for (int j = 0; j < IPL; ++j) {
+                float tx = sx[j], tq = sq[j];
+                tx += dpp(tx, std::integral_constant<int, 0xB1>{}); tq += dpp(tq, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+                tx += dpp(tx, std::integral_constant<int, 0x4E>{}); tq += dpp(tq, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+                tx += dpp(tx, std::integral_constant<int, 0x141>{}); tq += dpp(tq, std::integral_constant<int, 0x141>{});    // row_half_mirror
+                if (qpos == 0) { const int r = 8 * (l + j * NL) + sub; stat[2 * r] = tx; stat[2 * r + 1] = tq; }
+            }
+        }
+        if (l == 0) WS_STAMP(28);                               // loader done
     } else {
         // ------------------------------------------------------------------------------------------ consumer waves
+        if (wave == 0) WS_STAMP(32);                            // consumer entry
+        if constexpr (RES_EARLY) {
+            request_residual();
+            __builtin_amdgcn_sched_barrier(0);                  // (in FRONT of the weight ring)
+        }
         const int t0 = (y * NW + wave) * NT;                    // this wave's first 32-row weight tile
         const int KST = a.Ktot >> 4;                            // k steps of the whole contraction
         const h16 *wp = a.w + (long long)t0 * KST * 512;          // wave-uniform (SGPR) base of this wave's first tile
@@ -212,47 +358,41 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) ws_gload<NTW>(wr[j][i], voff[i], wp + (long long)kk * 512);
         }
-        int xoff[4];
+        unsigned xoff[4];                                       // LDS byte address of this lane's fragment slot of k step u (stage 0, token tile 0)
+        const unsigned lds0 = (unsigned)(size_t)L2D_LPTR(smem);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xoff[u] = l32 * 64 + ((((2 * u + lh) ^ ((l32 >> 1) & 7))) << 3);
-        // row statistics for the LayerNorm fold: token tile mt = wave (four consumer waves) is summed by this wave.  The tile's
-        // fragment is read from LDS a second time (wave-dependent address: selecting it among the four fragment registers the
-        // MFMAs use costs 12 v_cndmask per k step and ~30 registers): one more ds_read_b128 and 8 v_dot2 per k step
-        const int wm = wave & 3;
-        float sx = 0.f, sq = 0.f;
-        const h16x2 ones2 = {(h16)1.0f, (h16)1.0f};
-        int soff[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) soff[u] = xoff[u] + wm * 2048;
-
-        h16x8 xf[2][MT], xs[2];
+        for (int u = 0; u < 4; ++u) xoff[u] = lds0 + (l32 * 64 + ((((2 * u + lh) ^ ((l32 >> 1) & 7))) << 3)) * 2;
+        h16x8 xf[2][MT];
+        if (wave == 0) WS_STAMP(33);                            // weight ring requested
         __builtin_amdgcn_s_barrier();                           // stage 0 has landed
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xf[0][mt] = l2d_ld8(smem + xoff[0] + mt * 2048);
-        if constexpr (PRO) xs[0] = l2d_ld8(smem + soff[0]);
+        if (wave == 0) WS_STAMP(34);
+        ws_lread<0>(xf[0][0], xoff[0]); ws_lread<4096>(xf[0][1], xoff[0]); ws_lread<8192>(xf[0][2], xoff[0]); ws_lread<12288>(xf[0][3], xoff[0]);
 
         // one stage = 4 k steps on ring slots 4 p .. 4 p + 3.  MORE: another stage follows -- its barrier is met inside this stage's
         // last k step, after the stage's last fragment read, and the next stage's first fragments are fetched under that step's MFMAs
         auto do_stage = [&](auto pc, auto refill_c, int slot, bool more) {
             constexpr int p = decltype(pc)::value;
             constexpr bool REFILL = decltype(refill_c)::value;
-            const h16 *sb = smem + slot * STG;
+            const unsigned sb = slot * (STG * 2), nb = ((slot + 1) & (NS - 1)) * (STG * 2);       // byte offsets of this / the next stage
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 constexpr int j = 4 * p + 0;
+                // LDS queue of this wave, oldest first, when the MFMAs of step u start: this step's 4 fragments | the next step's 4
                 if (u < 3) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[(u + 1) & 1][mt] = l2d_ld8(sb + xoff[u + 1] + mt * 2048);
-                    if constexpr (PRO) xs[(u + 1) & 1] = l2d_ld8(sb + soff[u + 1]);
+                    const unsigned ad = xoff[u + 1] + sb;
+                    ws_lread<0>(xf[(u + 1) & 1][0], ad); ws_lread<4096>(xf[(u + 1) & 1][1], ad);
+                    ws_lread<8192>(xf[(u + 1) & 1][2], ad); ws_lread<12288>(xf[(u + 1) & 1][3], ad);
+                    ws_lwait<4>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
                 } else if (more) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // every fragment of this stage is in registers: meet the loader (it may refill this stage's slot) and fetch the
+                    // next stage's first fragments under this step's MFMAs
+                    ws_lwait<0>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
                     __builtin_amdgcn_s_barrier();
-                    const h16 *nb = smem + ((slot + 1) & (NS - 1)) * STG;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[0][mt] = l2d_ld8(nb + xoff[0] + mt * 2048);
-                    if constexpr (PRO) xs[0] = l2d_ld8(nb + soff[0]);
+                    const unsigned ad = xoff[0] + nb;
+                    ws_lread<0>(xf[0][0], ad); ws_lread<4096>(xf[0][1], ad); ws_lread<8192>(xf[0][2], ad); ws_lread<12288>(xf[0][3], ad);
+                } else {
+                    ws_lwait<0>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);              // (the next step's fragment reads stay in FRONT of this step's MFMAs)
                 // this k step's weight fragments have landed when only the younger requests are outstanding: NT per later k step
                 // of the ring (main loop: all 4 RDS - 1 of them; the last stages issue no refills and count down)
                 {
@@ -271,14 +411,6 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
 #undef WS_TAIL_WAIT
                     }
                 }
-                if constexpr (PRO) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const h16x2 pr = {xs[u & 1][2 * e], xs[u & 1][2 * e + 1]};
-                        sx = __builtin_amdgcn_fdot2(pr, ones2, sx, false);
-                        sq = __builtin_amdgcn_fdot2(pr, pr, sq, false);
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -293,6 +425,9 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 ++ks;
                 __builtin_amdgcn_sched_barrier(0);              // the refills stay HERE: 4 RDS - 1 k steps ahead of their use
             }
+#ifdef L2D_PROBES
+            { const int sdone = (ks >> 2) - c0 - 1; if (wave == 0 && sdone < 12) WS_STAMP(35 + 2 * sdone); }   // stage done (issue side)
+#endif
         };
         // main loop: RDS stages per iteration (static ring slots), every one of them followed by another stage
         int s = 0;
@@ -320,24 +455,19 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 }
             }
         }
+        if (wave == 0) WS_STAMP(60);                            // k loop done (issue side)
         // (the clamped duplicates of the last ring: nothing of this wave's is in flight beyond here)
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < 4 * RDS; j += 8)
                 ws_gdrain8(wr[j][i], wr[j + 1][i], wr[j + 2][i], wr[j + 3][i], wr[j + 4][i], wr[j + 5][i], wr[j + 6][i], wr[j + 7][i]);
-        if constexpr (PRO) {
-            const float tx = sx + __shfl_xor(sx, 32, 64), tq = sq + __shfl_xor(sq, 32, 64);
-            if (wave < 4 && lh == 0) { stat[(32 * wm + l32) * 2] = tx; stat[(32 * wm + l32) * 2 + 1] = tq; }
-        }
     }
 
     // ------------------------------------------------------------------------------------------------- epilogue
-    const int BNp = NW * NT * 32;                              // packed weight rows of this block
-    const int BNo = a.epi == 1 ? BNp >> 1 : BNp;               // output columns
-    const int nb_p = y * BNp, nb_o = y * BNo;
-    const bool cons = wave < NW;
+    if constexpr (!RES_EARLY) request_residual();
     __syncthreads();                                           // ring idle; the slice's row statistics are in LDS
+    if (wave == 0) WS_STAMP(61);                               // all waves done with the loop
 
     if (a.S > 1) {
         // split-K, reduction fused (protocol of igemm.hip): partial accumulators (and partial row statistics) leave as
@@ -365,10 +495,11 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's partials have been written through ...
         __syncthreads();                                        // ... every thread's have
-        unsigned int *flag = reinterpret_cast<unsigned int *>(stat + 2 * BM);
+        unsigned int *flag = reinterpret_cast<unsigned int *>(stat + 2 * BM);       // (16 floats between the statistics and `par`)
         if (tid == 0) *flag = atomicAdd(a.cnt + tile, 1u);
         __syncthreads();
         const bool last = (*flag == (unsigned int)(a.S - 1));
+        if (wave == 0) WS_STAMP(62);                            // partials parked, arrival known
         if (!last) return;
         if (tid == 0) atomicExch(a.cnt + tile, 0u);             // ready for the next launch that uses this counter
         if (cons) {
@@ -426,10 +557,10 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 const int tp = (wave * NT + i) * 32;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int ch = nb_p + tp + 8 * g4 + 4 * lh;
+                    const int ch = tp + 8 * g4 + 4 * lh;
                     f32x4 bb = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) bb = *reinterpret_cast<const f32x4 *>(a.bias + ch);
-                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(a.colsum + ch);
+                    if (a.bias) bb = *reinterpret_cast<const f32x4 *>(par + ch);
+                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + 256 + ch);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         float rsd = 1.f, nmr = 0.f;
@@ -454,19 +585,14 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
         return;
     }
 
+    if (wave == 0) WS_STAMP(59);                               // (last block: slabs summed) epilogue starts
     const int pitch = BNo + 8;                                 // halfs; row stride = 16 B mod 32 B
     if (cons) {
         float rsd[MT], nmr[MT];
-        const float *rb[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            rsd[mt] = 1.f; nmr[mt] = 0.f; rb[mt] = nullptr;
+            rsd[mt] = 1.f; nmr[mt] = 0.f;
             if (a.pro == 1) { rsd[mt] = stat[(32 * mt + l32) * 2]; nmr[mt] = stat[(32 * mt + l32) * 2 + 1]; }
-            if (a.rowbias) {                                    // one time-embedding row per rows_per_bias tokens (% 32 == 0)
-                int mm = m0 + 32 * mt;
-                if (mm >= a.M) mm = a.M - 1;
-                rb[mt] = a.rowbias + (long long)(mm / a.rows_per_bias) * a.ldrb;
-            }
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -476,10 +602,10 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 // groups (0,1) and (2,3) hold value / gate of the SAME channels in the same lane
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
-                    const int ch = nb_p + tp + 16 * g2 + 4 * lh;
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + ch), bg = *reinterpret_cast<const f32x4 *>(a.bias + ch + 8);
+                    const int ch = tp + 16 * g2 + 4 * lh;
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(par + ch), bg = *reinterpret_cast<const f32x4 *>(par + ch + 8);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f}, cg = {0.f, 0.f, 0.f, 0.f};
-                    if (a.pro == 1) { cv = *reinterpret_cast<const f32x4 *>(a.colsum + ch); cg = *reinterpret_cast<const f32x4 *>(a.colsum + ch + 8); }
+                    if (a.pro == 1) { cv = *reinterpret_cast<const f32x4 *>(par + 256 + ch); cg = *reinterpret_cast<const f32x4 *>(par + 256 + ch + 8); }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         h16x4 o;
@@ -495,14 +621,14 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
             } else {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int ch = nb_p + tp + 8 * g4 + 4 * lh;
+                    const int ch = tp + 8 * g4 + 4 * lh;
                     f32x4 bb = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) bb = *reinterpret_cast<const f32x4 *>(a.bias + ch);
-                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(a.colsum + ch);
+                    if (a.bias) bb = *reinterpret_cast<const f32x4 *>(par + ch);
+                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + 256 + ch);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         f32x4 b2 = bb;
-                        if (rb[mt]) b2 += *reinterpret_cast<const f32x4 *>(rb[mt] + ch);
+                        if (a.rowbias) b2 += *reinterpret_cast<const f32x4 *>(par + 512 + mt * 256 + ch);
                         h16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[i][mt][4 * g4 + e] * rsd[mt] + nmr[mt] * cs[e] + b2[e]);
@@ -512,12 +638,11 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
             }
         }
     }
+    if (wave == 0) WS_STAMP(57);                               // tile staged (this wave)
     __syncthreads();
-    // whole rows, 16 bytes per lane: thread -> (row rr + k RPP, 8-channel chunk cc); cc is the same for every row of a thread, which
-    // is what lets it keep per-channel GroupNorm sums in registers.  One pass per sample that overlaps the tile.
-    const int CPR = BNo >> 3, RPP = nthr / CPR;
-    const int rr = tid / CPR, cc = tid - rr * CPR;
-    const bool on = cons && rr < RPP;
+    if (wave == 0) WS_STAMP(58);                               // ... by every wave
+    // whole rows, 16 bytes per lane; cc is the same for every row of a thread, which is what lets it keep per-channel GroupNorm sums
+    // in registers.  One pass per sample that overlaps the tile (sample boundaries are multiples of 32 rows, RPP divides 32).
     const bool gn = a.gn1 != nullptr;
     const int rows = a.M - m0 < BM ? a.M - m0 : BM;
     const int segT = gn ? a.gnT : (1 << 30);
@@ -530,29 +655,22 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
         for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
         const h16x2 ones2 = {(h16)1.0f, (h16)1.0f};
         if (on) {
-            for (int r0 = lo + rr; r0 < hi; r0 += 4 * RPP) {
-                h16x8 rv[4];
+#pragma unroll
+            for (int k = 0; k < EITMAX; ++k) {
+                const int row = rr + k * RPP;
+                if (row < lo || row >= hi) continue;
+                h16x8 v = l2d_ld8(os + row * pitch + cc * 8);
                 if (a.res) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = r0 + k * RPP < hi ? r0 + k * RPP : r0;
-                        rv[k] = l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + cc * 8);
-                    }
+                    if (k < PF) v = v + resp[k < PF ? k : 0];
+                    else v = v + l2d_ld8(a.res + (long long)(m0 + row) * a.ldr + nb_o + cc * 8);
                 }
+                l2d_st8(a.out + (long long)(m0 + row) * a.ldo + nb_o + cc * 8, v);
+                if (gn) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = r0 + k * RPP;
-                    if (row >= hi) break;
-                    h16x8 v = l2d_ld8(os + row * pitch + cc * 8);
-                    if (a.res) v = v + rv[k];
-                    l2d_st8(a.out + (long long)(m0 + row) * a.ldo + nb_o + cc * 8, v);
-                    if (gn) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const h16x2 pr = {v[2 * e], v[2 * e + 1]};
-                            gs[e] = __builtin_amdgcn_fdot2(pr, ones2, gs[e], false);
-                            gq[e] = __builtin_amdgcn_fdot2(pr, pr, gq[e], false);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const h16x2 pr = {v[2 * e], v[2 * e + 1]};
+                        gs[e] = __builtin_amdgcn_fdot2(pr, ones2, gs[e], false);
+                        gq[e] = __builtin_amdgcn_fdot2(pr, pr, gq[e], false);
                     }
                 }
             }
@@ -578,35 +696,31 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
             __syncthreads();
         }
     }
+    if (wave == 0) WS_STAMP(63);                               // rows stored
 }
 
-template <int NT, int RDS, int NL, bool NTW, bool PRO, int MAXW>
+template <int NT, int RDS, int NL, bool NTW, int MAXW>
 static void launch_ws(const WsArgs &a, int nthr, size_t lds, hipStream_t s) {
     static bool attr_done[16] = {false};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 65536 && dev >= 0 && dev < 16 && !attr_done[dev]) {   // > 64 KB of dynamic LDS: opted into once per kernel and device
-        if (hipFuncSetAttribute((const void *)wsgemm_kernel<NT, RDS, NL, NTW, PRO, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)wsgemm_kernel<NT, RDS, NL, NTW, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess)
             attr_done[dev] = true;
         else
             (void)hipGetLastError();
     }
-    hipLaunchKernelGGL((wsgemm_kernel<NT, RDS, NL, NTW, PRO, MAXW>), dim3(a.nm * a.ny * a.S), dim3(nthr), lds, s, a);
+    hipLaunchKernelGGL((wsgemm_kernel<NT, RDS, NL, NTW, MAXW>), dim3(a.nm * a.ny * a.S), dim3(nthr), lds, s, a);
 }
 
 template <int NT, int RDS, int MAXW>
 static void launch_ws_v(const WsArgs &a, int NL, bool ntw, int nthr, size_t lds, hipStream_t s) {
-    const int v = (NL == 2 ? 4 : 0) | (ntw ? 2 : 0) | (a.pro == 1 ? 1 : 0);
-    constexpr bool P = MAXW <= 6;          // the LayerNorm fold exists for the 4-consumer geometries only (validated by the caller)
-    switch (v) {
-        case 0: launch_ws<NT, RDS, 1, false, false, MAXW>(a, nthr, lds, s); break;
-        case 1: launch_ws<NT, RDS, 1, false, P, MAXW>(a, nthr, lds, s); break;
-        case 2: launch_ws<NT, RDS, 1, true, false, MAXW>(a, nthr, lds, s); break;
-        case 3: launch_ws<NT, RDS, 1, true, P, MAXW>(a, nthr, lds, s); break;
-        case 4: launch_ws<NT, RDS, 2, false, false, MAXW>(a, nthr, lds, s); break;
-        case 5: launch_ws<NT, RDS, 2, false, P, MAXW>(a, nthr, lds, s); break;
-        case 6: launch_ws<NT, RDS, 2, true, false, MAXW>(a, nthr, lds, s); break;
-        default: launch_ws<NT, RDS, 2, true, P, MAXW>(a, nthr, lds, s); break;
+    if (NL == 1) {
+        if (ntw) launch_ws<NT, RDS, 1, true, MAXW>(a, nthr, lds, s);
+        else launch_ws<NT, RDS, 1, false, MAXW>(a, nthr, lds, s);
+    } else {
+        if (ntw) launch_ws<NT, RDS, 2, true, MAXW>(a, nthr, lds, s);
+        else launch_ws<NT, RDS, 2, false, MAXW>(a, nthr, lds, s);
     }
 }
 
@@ -633,6 +747,9 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     a.T = op->i[30];
     a.sT = op->l[0];
     a.eps = op->f[0];
+#ifdef L2D_PROBES
+    a.probe = g_wsgemm_probe;
+#endif
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     a.Ktot = a.taps * a.CinP;
     const int tiles = Nout > 0 ? Nout / 32 : 0;
@@ -642,18 +759,22 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     if (!a.x1 || !a.w || !a.zero || a.M <= 0 || a.M >= (1 << 22) || (a.taps != 1 && a.taps != 9) || !geom_ok || a.C1 <= 0 || (a.C1 % 64) ||
         a.C2 < 0 || (a.C2 % 64) || (a.C2 > 0 && !a.x2) || a.CinP != a.C1 + a.C2 || (a.ldx1 % 8) || a.ldx1 < a.C1 ||
         (a.C2 > 0 && ((a.ldx2 % 8) || a.ldx2 < a.C2)) || a.epi < 0 || a.epi > 1 || a.pro < 0 || a.pro > 1 ||
-        (a.pro == 1 && (!a.colsum || conv || NW != 4)) || (a.epi == 1 && (!a.bias || a.res || ntr != 0 || a.rowbias)) ||
+        (a.pro == 1 && (!a.colsum || conv)) || (a.epi == 1 && (!a.bias || a.res || ntr != 0 || a.rowbias)) ||
         (ntr < tiles && (!a.out || (a.ldo % 8))) || (a.res && (a.ldr % 8)) ||
         (conv && (B <= 0 || a.H <= 0 || a.W < 8 || a.H >= 32768 || a.W >= 32768 || a.M != B * a.H * a.W)) ||
         (a.rowbias && (a.ldrb <= 0 || a.rows_per_bias <= 0 || (a.rows_per_bias % 32))) ||
         (ntr > 0 && (!a.outT || a.T <= 0 || (a.T % 128) || (a.M % a.T) || (a.ldt % 8) || a.ldt < a.T)) ||
-        (a.S > 1 && (!a.ws || !a.cnt || ntr != 0 || a.S > a.Ktot / 64)) ||
+        (a.S > 1 && (!a.ws || !a.cnt || ntr != 0 || a.S > a.Ktot / 64)) || a.CinP > 32000 ||
         (((unsigned long long)a.x1 | (unsigned long long)a.x2 | (unsigned long long)a.w | (unsigned long long)a.out |
           (unsigned long long)a.res | (unsigned long long)a.outT | (unsigned long long)a.bias | (unsigned long long)a.colsum |
           (unsigned long long)a.rowbias | (unsigned long long)a.ws | (unsigned long long)a.zero) & 15)) {
         l2d_set_error("wsgemm(tag %d): invalid arguments (taps=%d M=%d C1=%d C2=%d CinP=%d Nout=%d ldo=%d epi=%d pro=%d NW=%d NT=%d NL=%d S=%d "
                       "ntr=%d T=%d H=%d W=%d)", op->tag, a.taps, a.M, a.C1, a.C2, a.CinP, Nout, a.ldo, a.epi, a.pro, NW, NT, NL, a.S, ntr,
                       a.T, a.H, a.W);
+        return L2D_EINVAL;
+    }
+    if ((long long)(a.M + 128) * a.ldx1 * 2 >= (1ll << 31) || (a.C2 > 0 && (long long)(a.M + 128) * a.ldx2 * 2 >= (1ll << 31))) {
+        l2d_set_error("wsgemm(tag %d): activation tensor too large for 32-bit row offsets (M=%d)", op->tag, a.M);
         return L2D_EINVAL;
     }
     const int BM = 128, BNp = NW * NT * 32, BNo = a.epi == 1 ? BNp / 2 : BNp, nthr = 64 * NW;
@@ -682,7 +803,7 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     if (ntr > 0 && (size_t)BNp * (BM + 8) * 2 > epi) epi = (size_t)BNp * (BM + 8) * 2;
     const size_t body = ring > epi ? ring : epi;
     a.stat_off = (int)((body + 255) & ~(size_t)255);
-    const size_t lds = (size_t)a.stat_off + 2 * BM * 4 + 64;
+    const size_t lds = (size_t)a.stat_off + 2 * BM * 4 + 64 + 6 * 256 * 4;      // + bias | column sums | 4 time-embedding rows
     if (lds > 163840 || (long long)a.nm * a.ny * a.S >= (1 << 24) || (long long)a.S * (BM * BNp + 2 * BM) * 4 >= (1ll << 31)) {
         l2d_set_error("wsgemm(tag %d): tile does not fit (LDS %zu bytes, %d x %d x %d blocks)", op->tag, lds, a.nm, a.ny, a.S);
         return L2D_EINVAL;

@@ -124,10 +124,11 @@ _ZERO_PAGES = {}
 
 
 def zero_page(device) -> torch.Tensor:
-    """256 bytes of zeros per device: the DMA source for conv padding / ragged rows / channel tails (igemm.hip)."""
+    """64 KB of zeros per device: the DMA source for conv padding / ragged rows / channel tails (igemm.hip reads 16 bytes of it;
+    wsgemm.hip walks up to 2 CinP + 128 bytes of it with the same per-stage stride as real rows)."""
     key = str(device)
     if key not in _ZERO_PAGES:
-        _ZERO_PAGES[key] = torch.zeros(128, dtype=torch.float16, device=device)
+        _ZERO_PAGES[key] = torch.zeros(32768, dtype=torch.float16, device=device)
     return _ZERO_PAGES[key]
 
 
@@ -409,7 +410,7 @@ def _ws_lds(NW, NT, epi, ntr, gn):
     ep = WS_BM * (BNo + 8) * 2 + ((64 * NW * 32 + BNo * 4) if gn else 0)
     if ntr:
         ep = max(ep, BNp * (WS_BM + 8) * 2)
-    return ((max(ring, ep) + 255) // 256) * 256 + 2 * WS_BM * 4 + 64
+    return ((max(ring, ep) + 255) // 256) * 256 + 2 * WS_BM * 4 + 64 + 6 * 256 * 4
 
 
 def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0, taps: int = 1):
@@ -427,7 +428,7 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
     cands = []
     for nt in (1, 2):
         for nw in range(1, (4 if nt == 2 else 8) + 1):
-            if tiles % (nw * nt) or (ntr // 32) % (nw * nt) or (pro == 1 and nw != 4):
+            if tiles % (nw * nt) or (ntr // 32) % (nw * nt):
                 continue
             if _ws_lds(nw, nt, epi, ntr, True) > 163840:
                 continue

@@ -118,6 +118,12 @@ class HipStreamingUNet:
         self.config = SimpleNamespace(in_channels=cfg.in_channels)      # read by the reference wrapper (:524)
         self.device_name = "dry-run" if ops.DRY_RUN else _lib.device_name()   # raises unless a gfx950 is present
         self.mm_layout = motion_module_layout(cfg, height, width)
+        # levels whose stream batch is small enough for the weight-streaming GEMM (wsgemm.hip): N * T tokens <= L2D_WSGEMM_MAX_M and
+        # samples made of whole 32-token tiles.  Decides the PACKING of those levels' layers (and with it the plan's kernels).
+        ws_on = os.environ.get("L2D_WSGEMM", "0") != "0"
+        ws_max = int(os.environ.get("L2D_WSGEMM_MAX_M", "512"))
+        self.ws_levels = [ws_on and denoising_steps_num * (height >> l) * (width >> l) <= ws_max and ((height >> l) * (width >> l)) % 32 == 0
+                          for l in range(cfg.num_levels)]
         if isinstance(state_dict, HipStreamingUNet):
             o = state_dict
             if (o.cfg, o.h, o.w, o.device) != (cfg, self.h, self.w, self.device):
@@ -164,15 +170,31 @@ class HipStreamingUNet:
         use_rg = os.environ.get("L2D_ROWGEMM", "1") != "0"     # A/B knob: 0 = every linear layer on igemm + separate norm launches
         RG_PLAIN_MAX_K = int(os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"))
         RG_FF1_MAX_K = int(os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))     # A/B knob: GEGLU GEMMs wider than this stay on igemm
+        ws_lv = self.ws_levels
 
         def rg_ok(wname):
             n, k = sd[wname].shape[0], sd[wname][0].numel()
             return use_rg and ops.rowgemm_ok(n, k)
 
-        def lin(name, bias=True, norm=None, old=False):
-            """Linear layer `name`; `norm` = the LayerNorm / GroupNorm whose output feeds it.  Token-row GEMM packing
-            (rowgemm.hip: fragment order, the norm's affine folded into weight and bias) when the shape allows, else -- and
-            with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
+        def ws_ok(wname, lvl):
+            """the weight-streaming GEMM (wsgemm.hip) takes this layer: a level of few tokens, 32-row weight tiles, 64-column chunks"""
+            n, k = sd[wname].shape[0], sd[wname][0].numel()
+            return lvl is not None and ws_lv[lvl] and n % 32 == 0 and k % 64 == 0
+
+        def lin(name, bias=True, norm=None, old=False, lvl=None, gnorm=False):
+            """Linear layer `name`; `norm` = the LayerNorm (or, `gnorm`, GroupNorm) whose output feeds it.  At the few-token levels
+            (`lvl` in self.ws_levels) the weight-streaming packing (wsgemm.hip: fragment order, a LayerNorm folded into weight,
+            bias and column sums) -- except behind a GroupNorm, whose per-group scale cannot move to the accumulator side.
+            Else token-row GEMM packing (rowgemm.hip: fragment order, the norm's affine folded into weight and bias) when the shape
+            allows, else -- and with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
+            if ws_ok(name + ".weight", lvl) and not gnorm:
+                W[name + ".ww"], wb, wcs = ops.pack_wsgemm(g(name + ".weight"), g(name + ".bias") if bias else None,
+                                                           g(norm + ".weight") if norm else None, g(norm + ".bias") if norm else None)
+                if wb is not None:
+                    W[name + ".wb"] = wb
+                if wcs is not None:
+                    W[name + ".wcs"] = wcs
+                return
             # Row GEMM where it fuses a norm, and for the narrow levels (K <= 640).  A plain Linear at K = 1280 stays on the
             # implicit-GEMM kernel: with 32-token row tiles every block ingests its whole weight band (80 KB per 32-row tile), and
             # the probe (profiles/round3_b_rowgemm_block_phases_before.txt) shows those launches bound by ~30 B/clk of ingest per CU.
@@ -191,25 +213,49 @@ class HipStreamingUNet:
             W[name + ".g"] = g(name + ".weight").to(torch.float16).contiguous()
             W[name + ".beta"] = g(name + ".bias").to(torch.float16).contiguous()
 
-        def ff(name, norm, old=False):
+        def ff(name, norm, old=False, lvl=None):
             pw, pb = name + ".net.0.proj.weight", name + ".net.0.proj.bias"
+            if ws_ok(pw, lvl) and sd[pw].shape[0] % 256 == 0:          # (4 consumer waves x 32-row tiles behind the LayerNorm fold; GEGLU pairs)
+                W[name + ".ww1"], W[name + ".wb1"], W[name + ".wcs1"] = ops.pack_wsgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"),
+                                                                                         geglu=True)
+                lin(name + ".net.2", old=old, lvl=lvl)
+                return
             rg = rg_ok(pw) and sd[pw].shape[0] % 64 == 0 and sd[pw][0].numel() <= RG_FF1_MAX_K
             if rg:
                 W[name + ".rw1"], W[name + ".rb1"] = ops.pack_rowgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"), geglu=True)
             if not rg or old:
                 W[name + ".w1"], W[name + ".b1"] = ops.pack_geglu(g(pw), g(pb))
-            lin(name + ".net.2", old=old)
+            lin(name + ".net.2", old=old, lvl=lvl)
 
         self.temb_names, self.temb_offsets = [], {}
         temb_w, temb_b = [], []
         self.text_offsets = {}
         text_k, text_v = [], []
 
+        def level_of(name):
+            if name.startswith("mid_block"):
+                return cfg.num_levels - 1
+            lvl = int(name.split(".")[1])
+            return cfg.num_levels - 1 - lvl if name.startswith("up_blocks") else lvl
+
+        def conv3ws(name, lvl):
+            """resnet 3x3 conv: weight-streaming packing at the few-token levels, else the implicit-GEMM / patch-conv packing"""
+            cw = sd[name + ".weight"]
+            if ws_lv[lvl] and cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0:
+                W[name + ".ww"] = ops.pack_wsgemm_conv3x3(g(name + ".weight"))
+                W[name + ".b"] = ops.f32(g(name + ".bias"))
+            else:
+                conv3(name)
+
         def resnet(name):
-            norm(name + ".norm1"); conv3(name + ".conv1"); norm(name + ".norm2"); conv3(name + ".conv2")
-            if (name + ".conv_shortcut.weight") in sd:        # (two-input concat GEMM: implicit-GEMM kernel)
-                W[name + ".conv_shortcut.w"] = ops.pack_linear(g(name + ".conv_shortcut.weight"))
-                W[name + ".conv_shortcut.b"] = ops.f32(g(name + ".conv_shortcut.bias"))
+            lvl = level_of(name)
+            norm(name + ".norm1"); conv3ws(name + ".conv1", lvl); norm(name + ".norm2"); conv3ws(name + ".conv2", lvl)
+            if (name + ".conv_shortcut.weight") in sd:        # (two-input concat GEMM)
+                if ws_ok(name + ".conv_shortcut.weight", lvl):
+                    lin(name + ".conv_shortcut", lvl=lvl)
+                else:
+                    W[name + ".conv_shortcut.w"] = ops.pack_linear(g(name + ".conv_shortcut.weight"))
+                    W[name + ".conv_shortcut.b"] = ops.f32(g(name + ".conv_shortcut.bias"))
             self.temb_offsets[name] = sum(t.shape[0] for t in temb_w)
             temb_w.append(g(name + ".time_emb_proj.weight").to(torch.float16))
             temb_b.append(g(name + ".time_emb_proj.bias").float())
@@ -219,35 +265,39 @@ class HipStreamingUNet:
             # tile (its transposed V output and GroupNorm prologue need that): it keeps the implicit-GEMM packing as well
             # (likewise any level of THIS instance where T % 32 != 0: small test latents; a packed-weight file written there
             # holds both forms, one written at an SD resolution holds the second form for the mid block only)
-            lvl = cfg.num_levels - 1 if name.startswith("mid_block") else int(name.split(".")[1])
-            if name.startswith("up_blocks"):
-                lvl = cfg.num_levels - 1 - lvl
-            old = name.startswith("mid_block") or ((self.h >> lvl) * (self.w >> lvl)) % 32 != 0
+            lvl = level_of(name)
+            Tl = (self.h >> lvl) * (self.w >> lvl)
+            old = name.startswith("mid_block") or Tl % 32 != 0
             b = name + ".transformer_blocks.0"
-            norm(name + ".norm"); lin(name + ".proj_in", norm=name + ".norm", old=old); lin(name + ".proj_out", old=old)
+            norm(name + ".norm"); lin(name + ".proj_in", norm=name + ".norm", old=old, gnorm=True); lin(name + ".proj_out", old=old, lvl=lvl)
             for n in ("norm1", "norm2", "norm3"):
                 norm(b + "." + n)
             wq, wk, wv = (g(b + f".attn1.to_{c}.weight") for c in "qkv")
-            if rg_ok(b + ".attn1.to_q.weight"):
+            if ws_ok(b + ".attn1.to_q.weight", lvl) and Tl % 128 == 0 and wq.shape[0] % 128 == 0:
+                # q | k | v in one weight-streaming launch behind norm1 (V leaves transposed: a sample is whole 128-token tiles)
+                W[b + ".attn1.qkv.ww"], W[b + ".attn1.qkv.wb"], W[b + ".attn1.qkv.wcs"] = ops.pack_wsgemm(
+                    torch.cat([wq, wk, wv], 0), None, g(b + ".norm1.weight"), g(b + ".norm1.bias"))
+            elif rg_ok(b + ".attn1.to_q.weight"):
                 # q | k | v in one launch behind norm1 (V leaves transposed): rowgemm.hip
                 W[b + ".attn1.qkv.rw"], W[b + ".attn1.qkv.rb"] = ops.pack_rowgemm(
                     torch.cat([wq, wk, wv], 0), None, g(b + ".norm1.weight"), g(b + ".norm1.bias"))
-            if not rg_ok(b + ".attn1.to_q.weight") or old:
+            if (b + ".attn1.qkv.ww") not in W and (not rg_ok(b + ".attn1.to_q.weight") or old):
                 W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([wq, wk], 0))
                 W[b + ".attn1.v"] = ops.pack_linear(wv)
-            lin(b + ".attn1.to_out.0", old=old)
-            lin(b + ".attn2.to_q", bias=False, norm=b + ".norm2", old=old)
+            lin(b + ".attn1.to_out.0", old=old, lvl=lvl)
+            lin(b + ".attn2.to_q", bias=False, norm=b + ".norm2", old=old, lvl=(lvl if wq.shape[0] % 128 == 0 else None))
             self.text_offsets[name] = sum(t.shape[0] for t in text_k)
             text_k.append(g(b + ".attn2.to_k.weight").to(torch.float16))
             text_v.append(g(b + ".attn2.to_v.weight").to(torch.float16))
-            lin(b + ".attn2.to_out.0", old=old)
-            ff(b + ".ff", b + ".norm3", old=old)
+            lin(b + ".attn2.to_out.0", old=old, lvl=lvl)
+            ff(b + ".ff", b + ".norm3", old=old, lvl=lvl)
 
         self.pe_tables = {}
 
         def motion(name, C):
             t = name + ".temporal_transformer"
-            norm(t + ".norm"); lin(t + ".proj_in", norm=t + ".norm"); lin(t + ".proj_out")
+            lvl = level_of(name)
+            norm(t + ".norm"); lin(t + ".proj_in", norm=t + ".norm", gnorm=True); lin(t + ".proj_out", lvl=lvl)
             b = t + ".transformer_blocks.0"
             L = cfg.window_size
             if C not in self.pe_tables:
@@ -256,7 +306,10 @@ class HipStreamingUNet:
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
                 wq, wk, wv = g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")
-                if rg_ok(a + ".to_q.weight"):
+                if ws_ok(a + ".to_q.weight", lvl) and (3 * wq.shape[0]) % 128 == 0:
+                    W[a + ".qkv.ww"], W[a + ".qkv.wb"], W[a + ".qkv.wcs"] = ops.pack_wsgemm(
+                        torch.cat([wq, wk, wv], 0), None, g(b + f".norms.{j}.weight"), g(b + f".norms.{j}.bias"))
+                elif rg_ok(a + ".to_q.weight"):
                     W[a + ".qkv.rw"], W[a + ".qkv.rb"] = ops.pack_rowgemm(
                         torch.cat([wq, wk, wv], 0), None, g(b + f".norms.{j}.weight"), g(b + f".norms.{j}.bias"))
                 else:
@@ -264,10 +317,10 @@ class HipStreamingUNet:
                 # pre-projected positional encodings (reference prepare_pe_buffer, stream_motion_module.py:79-97)
                 for nm, w_ in (("q_pe", wq), ("k_pe", wk), ("v_pe", wv)):
                     W[a + "." + nm] = (pe @ w_.float().t()).to(torch.float16).contiguous()
-                lin(a + ".to_out.0")
+                lin(a + ".to_out.0", lvl=lvl)
                 norm(b + f".norms.{j}")
             norm(b + ".ff_norm")
-            ff(b + ".ff", b + ".ff_norm")
+            ff(b + ".ff", b + ".ff_norm", lvl=lvl)
 
         conv3("conv_in")
         conv3("flow_conv_in.conv_in")
@@ -372,7 +425,7 @@ class HipStreamingUNet:
         # They run when the conditioning changes (first frame, update_prompt, a new warm-up row), not every frame.
         cond_pl = _lib.OpList()
         st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, cond_pl=cond_pl, cond_key=None, arena=ar, tattn_ops=[], warm=False,
-                             ident={}, rg=os.environ.get("L2D_ROWGEMM", "1") != "0")
+                             ident={}, rg=os.environ.get("L2D_ROWGEMM", "1") != "0", ws=any(self.ws_levels))
         cur = [cond_pl]
 
         def add(opk):
@@ -482,6 +535,15 @@ class HipStreamingUNet:
             return out
 
         def conv3(x: _Act, name, stride=1, ups=0, epi=0, res: Optional[_Act] = None, rowbias=None) -> _Act:
+            if use_ws(name):
+                # resnet conv at a few-token level: weight-streaming GEMM over (tap, channel chunk) stages (wsgemm.hip)
+                assert stride == 1 and not ups and epi == 0
+                cout = W[name + ".b"].numel()
+                out = new_act(cout, x.H, x.W)
+                out.producer = wslin(x.buf, B * x.H * x.W, x.C, name + ".ww", out.buf, cout, T=x.H * x.W, bias=W[name + ".b"],
+                                     res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0), taps=9, Bc=B, H=x.H,
+                                     Wd=x.W, rowbias_off=rowbias)
+                return out
             wt = W[name + ".w"]
             cout = wt.shape[0]
             cinp = wt.shape[1] // 9
@@ -528,11 +590,47 @@ class HipStreamingUNet:
             return add(ops.rowgemm(xbuf, wt, outbuf, M=M, K=K, Nout=wt.numel() // K, ldx=(ldx or K), ldo=ldo, bias=W.get(bkey),
                                    res=res, ldr=ldr, **kw))
 
+        def wslin(xbuf, M, C1, wkey, outbuf, ldo, *, T, bias=None, colsum=None, res=None, ldr=0, x2buf=None, C2=0, epi=0, pro=0,
+                  taps=1, Bc=1, H=1, Wd=1, rowbias_off=None, out_t=None, ntr=0, ldt=0, stt=0):
+            """one weight-streaming GEMM launch (wsgemm.hip) on weights packed by ops.pack_wsgemm / pack_wsgemm_conv3x3; the split-K
+            slabs come from the arena (released right after: stream order makes the reuse safe), the arrival counters from the
+            plan's counter block"""
+            wt = W[wkey]
+            Ktot = taps * (C1 + C2)
+            nout = wt.numel() // Ktot
+            sched = ops.wsgemm_schedule(M, Ktot, nout, ntr, epi, pro, taps)
+            NW_, NT_, NL_, S_, ntw_ = sched
+            ws_buf, kw = None, {}
+            if S_ > 1:
+                n_ws, n_cnt = ops.wsgemm_sizes(M, nout, NW_, NT_, S_)
+                ws_buf = ar.alloc(n_ws, torch.float32)
+                kw = dict(ws=ws_buf, cnt=st.sk_cnt, cnt_off=st.sk_used)
+                st.sk_used += n_cnt
+            if rowbias_off is not None:
+                kw.update(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(T if mode == "stream" else B * T))
+            op_ = add(ops.wsgemm(xbuf, wt, outbuf, M=M, Nout=nout, C1=C1, ldx1=C1, ldo=ldo, x2=x2buf, C2=C2, ldx2=C2, bias=bias, colsum=colsum,
+                                 res=res, ldr=ldr, taps=taps, B=Bc, H=H, W=Wd, epi=epi, pro=pro, eps=1e-5, T=T, out_t=out_t, ntr=ntr, ldt=ldt,
+                                 st=stt, sched=sched, **kw))
+            if rowbias_off is not None:
+                op_.p[4] = st.temb_all.data_ptr() + 4 * rowbias_off
+            ar.release(ws_buf)
+            return op_
+
+        def use_ws(key) -> bool:
+            return st.ws and (key + ".ww") in W
+
         def use_rg(key) -> bool:
             return st.rg and (key + ".rw") in W
 
         def linear(x: _Act, name, bias=True, res: Optional[_Act] = None, wkey=None, x2: Optional[_Act] = None, **kw) -> _Act:
             """kw: pro / eps / T / G / gn_acc_ptr of a fused norm prologue (row GEMM only)"""
+            if wkey is None and use_ws(name) and not kw:
+                nout = W[name + ".ww"].numel() // (x.C + (x2.C if x2 is not None else 0))
+                out = new_act(nout, x.H, x.W)
+                out.producer = wslin(x.buf, B * x.H * x.W, x.C, name + ".ww", out.buf, nout, T=x.H * x.W, bias=W.get(name + ".wb"),
+                                     res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
+                                     x2buf=(x2.buf if x2 is not None else None), C2=(x2.C if x2 is not None else 0))
+                return out
             if x2 is None and wkey is None and use_rg(name):
                 nout = W[name + ".rw"].numel() // x.C
                 out = new_act(nout, x.H, x.W)
@@ -577,6 +675,13 @@ class HipStreamingUNet:
 
         def geglu_ff(x: _Act, name, res: _Act, nname=None) -> _Act:
             """x: the un-normalised input when `nname` names the LayerNorm to fuse (row GEMM), else the normalised one"""
+            if nname is not None and st.ws and (name + ".ww1") in W:
+                c4 = W[name + ".ww1"].numel() // x.C // 2
+                hid = new_act(c4, x.H, x.W)
+                wslin(x.buf, B * x.H * x.W, x.C, name + ".ww1", hid.buf, c4, T=x.H * x.W, bias=W[name + ".wb1"], colsum=W[name + ".wcs1"], epi=1, pro=1)
+                out = linear(hid, name + ".net.2", res=res)
+                free(hid)
+                return out
             if nname is not None:
                 c4 = W[name + ".rw1"].numel() // x.C // 2
                 hid = new_act(c4, x.H, x.W)
@@ -591,7 +696,7 @@ class HipStreamingUNet:
             c4 = w1.shape[0] // 2
             hid = new_act(c4, x.H, x.W)
             linear_raw(x.buf, B * x.H * x.W, x.C, x.C, w1, hid.buf, c4, bias=W[name + ".b1"], epi=1)
-            out = linear(hid, name + ".net.2", res=res, **({} if use_rg(name + ".net.2") else dict(wkey=name + ".net.2.w")))
+            out = linear(hid, name + ".net.2", res=res, **({} if (use_rg(name + ".net.2") or use_ws(name + ".net.2")) else dict(wkey=name + ".net.2.w")))
             free(hid)
             return out
 
@@ -601,7 +706,7 @@ class HipStreamingUNet:
             free(hn)
             h2 = gn(h1, name + ".norm2", cfg.norm_eps, True)
             free(h1)
-            if (name + ".conv_shortcut.w") in W:
+            if (name + ".conv_shortcut.w") in W or (name + ".conv_shortcut.ww") in W:
                 sc = linear(x, name + ".conv_shortcut", x2=skip)
                 out = conv3(h2, name + ".conv2", res=sc)
                 free(sc)
@@ -616,13 +721,13 @@ class HipStreamingUNet:
             d = C // cfg.num_heads
             b = name + ".transformer_blocks.0"
             rg = use_rg(b + ".attn1.qkv") and T % 32 == 0         # (else: the implicit-GEMM path with separate norm launches)
+            rg_in = use_rg(name + ".proj_in") and T % 32 == 0
             ldvt = round_up(T, 8)
-            if rg:
+            # every linear layer picks its kernel by the packed form it finds: weight-streaming (.ww, few-token levels), token-row
+            # (.rw) or implicit GEMM (.w)
+            lin = lambda a_, nm, **k_: linear(a_, nm, **k_) if (use_ws(nm) or use_rg(nm)) else linear(a_, nm, wkey=nm + ".w", **k_)
+            if rg_in:
                 y = gn_linear(x, name + ".norm", cfg.transformer_norm_eps, name + ".proj_in")
-                # --- self attention: norm1 -> q | k | V^T in ONE launch
-                qk = ar.alloc(B * T * 2 * C)
-                vt = ar.alloc(B * C * ldvt)
-                ln_rowlin(y, b + ".attn1.qkv", qk, 2 * C, T=T, out_t=vt, ntr=C, ldt=ldvt, st=C * ldvt)
             else:
                 if (name + ".proj_in.w") not in W:
                     raise ValueError(f"{name}: T = {T} tokens per sample is no multiple of 32 at this level and the packed weights "
@@ -631,10 +736,17 @@ class HipStreamingUNet:
                 hn = gn(x, name + ".norm", cfg.transformer_norm_eps, False)
                 y = linear(hn, name + ".proj_in", wkey=name + ".proj_in.w")
                 free(hn)
+            # --- self attention: norm1 -> q | k | V^T
+            qk = ar.alloc(B * T * 2 * C)
+            vt = ar.alloc(B * C * ldvt)
+            if use_ws(b + ".attn1.qkv"):
+                wslin(y.buf, B * T, C, b + ".attn1.qkv.ww", qk, 2 * C, T=T, bias=W.get(b + ".attn1.qkv.wb"), colsum=W[b + ".attn1.qkv.wcs"], pro=1,
+                      out_t=vt, ntr=C, ldt=ldvt, stt=C * ldvt)
+            elif rg:
+                ln_rowlin(y, b + ".attn1.qkv", qk, 2 * C, T=T, out_t=vt, ntr=C, ldt=ldvt, st=C * ldvt)
+            else:
                 n1 = layernorm(y, b + ".norm1")
-                qk = ar.alloc(B * T * 2 * C)
                 linear_raw(n1.buf, B * T, C, C, W[b + ".attn1.qk"], qk, 2 * C)
-                vt = ar.alloc(B * C * ldvt)
                 # V^T[b] = Wv . n1[b]^T : the same GEMM with operand roles swapped (tokens act as "channels")
                 wv = W[b + ".attn1.v"]
                 gemm(wv, n1.buf, vt, M=C, Nout=T, C1=C, ldx1=wv.shape[1], CinP=C, ldo=ldvt, batch=B, sx1=0,
@@ -644,14 +756,16 @@ class HipStreamingUNet:
             add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
                                ldo=C, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, k_off=C))
             ar.release(qk); ar.release(vt)
-            lin = (lambda a_, nm, **k_: linear(a_, nm, **k_)) if rg else (lambda a_, nm, **k_: linear(a_, nm, wkey=nm + ".w", **k_))
             y2 = lin(ao, b + ".attn1.to_out.0", res=y)
             free(ao); free(y)
             # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start)
-            if rg:
-                q2 = new_act(C, x.H, x.W)
+            q2 = new_act(C, x.H, x.W)
+            if use_ws(b + ".attn2.to_q"):
+                wslin(y2.buf, B * T, C, b + ".attn2.to_q.ww", q2.buf, C, T=T, bias=W.get(b + ".attn2.to_q.wb"), colsum=W[b + ".attn2.to_q.wcs"], pro=1)
+            elif use_rg(b + ".attn2.to_q") and T % 32 == 0:
                 ln_rowlin(y2, b + ".attn2.to_q", q2.buf, C)
             else:
+                free(q2)
                 n2 = layernorm(y2, b + ".norm2")
                 q2 = linear(n2, b + ".attn2.to_q", bias=False, wkey=b + ".attn2.to_q.w")
                 free(n2)
@@ -664,7 +778,7 @@ class HipStreamingUNet:
             free(q2)
             y3 = lin(ao, b + ".attn2.to_out.0", res=y2)
             free(ao); free(y2)
-            if rg and (b + ".ff.rw1") in W:
+            if (st.ws and (b + ".ff.ww1") in W) or (st.rg and T % 32 == 0 and (b + ".ff.rw1") in W):
                 y4 = geglu_ff(y3, b + ".ff", res=y3, nname=b + ".norm3")
             else:
                 n3 = layernorm(y3, b + ".norm3")
@@ -683,7 +797,9 @@ class HipStreamingUNet:
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
                 qkv = ar.alloc(B * T * 3 * C)
-                if use_rg(a + ".qkv"):
+                if use_ws(a + ".qkv"):
+                    wslin(y.buf, B * T, C, a + ".qkv.ww", qkv, 3 * C, T=T, bias=W.get(a + ".qkv.wb"), colsum=W[a + ".qkv.wcs"], pro=1)
+                elif use_rg(a + ".qkv"):
                     ln_rowlin(y, a + ".qkv", qkv, 3 * C)
                 else:
                     nrm = layernorm(y, b + f".norms.{j}")
@@ -704,7 +820,7 @@ class HipStreamingUNet:
                 y2 = linear(ao, a + ".to_out.0", res=y)
                 free(ao); free(y)
                 y = y2
-            if use_rg(b + ".ff") or (st.rg and (b + ".ff.rw1") in W):
+            if (st.ws and (b + ".ff.ww1") in W) or use_rg(b + ".ff") or (st.rg and (b + ".ff.rw1") in W):
                 y2 = geglu_ff(y, b + ".ff", res=y, nname=b + ".ff_norm")
             else:
                 nrm = layernorm(y, b + ".ff_norm")

@@ -47,7 +47,7 @@ def _geoms(tiles, ntr_tiles=0, pro=0):
     out = []
     for nt in (1, 2):
         for nw in range(1, (4 if nt == 2 else 8) + 1):
-            if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0 and not (pro == 1 and nw != 4):
+            if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0:
                 out.append((nw, nt))
     return out
 
@@ -109,7 +109,7 @@ def test_wsgemm_layernorm_fold(L, M, C, N):
         ref = F.layer_norm(x.float(), (C,), gm.float(), bt.float(), 1e-5) @ w.float().t()
         wp, bp, cs = L.pack_wsgemm(w.to(DEV), None, gm.to(DEV), bt.to(DEV))
         assert bp is not None and cs is not None
-        for nw, nt in _geoms(N // 32, pro=1)[:4]:
+        for nw, nt in _geoms(N // 32, pro=1)[::2]:
             for S in (1, 2):
                 if S > C // 64:
                     continue
@@ -131,7 +131,7 @@ def test_wsgemm_geglu_with_layernorm(L, M, C):
     ref = h[:, :4 * C] * F.gelu(h[:, 4 * C:])
     wp, bp, cs = L.pack_wsgemm(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV), geglu=True)
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
-    for sched in ((4, 1, 1, 1, False), (4, 2, 1, 1, True), (4, 1, 2, 1, True), (4, 2, 2, 2, False)):
+    for sched in ((4, 1, 1, 1, False), (4, 2, 1, 1, True), (2, 1, 2, 1, True), (8, 1, 2, 1, False), (1, 2, 1, 1, False), (4, 2, 2, 2, False)):
         if (8 * C // 32) % (sched[0] * sched[1]) or sched[3] > C // 64:
             continue
         L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp, colsum=cs, pro=1, eps=1e-5, epi=1,
@@ -141,7 +141,8 @@ def test_wsgemm_geglu_with_layernorm(L, M, C):
     # GEGLU without a norm in front (pro = 0)
     h0 = x.float() @ w.float().t() + b
     wp0, bp0, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV), geglu=True)
-    L.run(L.wsgemm(x.to(DEV), wp0, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp0, epi=1))
+    sched = L.wsgemm_schedule(M, C, 8 * C, epi=1)
+    L.run(L.wsgemm(x.to(DEV), wp0, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp0, epi=1, sched=sched, **_split_bufs(L, M, 8 * C, sched)))
     torch.cuda.synchronize()
     check(out, h0[:, :4 * C] * F.gelu(h0[:, 4 * C:]), what="GEGLU")
 

@@ -174,7 +174,7 @@ def main():
         tiles = N // 32
         rows = []
         for nw, nt in ((1, 1), (2, 1), (4, 1), (8, 1), (5, 1), (2, 2), (4, 2)):
-            if tiles % (nw * nt) or (pro == 1 and nw != 4):
+            if tiles % (nw * nt):
                 continue
             ny = tiles // (nw * nt)
             for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 30):

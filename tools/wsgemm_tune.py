@@ -1,0 +1,107 @@
+"""Pick the (NW, NT, NL, S) schedule of every wsgemm shape of a configuration from IN-FRAME timings, in one process.
+
+    python tools/wsgemm_tune.py [--height 512 --width 512 --denoise-steps 2 --window 16] [--out live2diff_amd/wsgemm_tuned.json]
+
+For each candidate schedule the stream plan is rebuilt with that schedule forced on every wsgemm launch it fits
+(L2D_WSGEMM_FORCE; the split-K workspaces depend on it) and replayed with `l2d_time_each` (an event in front of every launch: each
+launch is timed with its real neighbours and cold weights); the per-shape winner is kept when it beats the default schedule by
+>= 3 %, and the table is merged into the JSON that ops.wsgemm_schedule reads."""
+import argparse
+import collections
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("L2D_WSGEMM", "1")
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=2)
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", default=os.path.join(ROOT, "live2diff_amd", "wsgemm_tuned.json"))
+    ap.add_argument("--report", default="")
+    args = ap.parse_args()
+    from live2diff_amd import _lib, ops
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import device_random_state_dict
+    dev = torch.device("cuda", 0)
+    cfg = sd15_config(window_size=args.window, sink_size=(4 if args.window == 12 else 8))
+    N, h, w = args.denoise_steps, args.height // 8, args.width // 8
+    unet = HipStreamingUNet(device_random_state_dict(cfg, dev), cfg, h, w, N, device=dev)
+    kv = unet.prepare_cache(N)
+    for c in kv:
+        c.normal_()
+
+    def key_of(op):
+        i = op.i
+        return f"{i[0]},{i[13]},{i[0] * (i[1] + i[2])},{i[14]},{i[21] * 32},{i[19]},{i[20]}"
+
+    def measure(force):
+        if force is None:
+            os.environ.pop("L2D_WSGEMM_FORCE", None)
+        else:
+            os.environ["L2D_WSGEMM_FORCE"] = ",".join(str(v) for v in force)
+        unet._plans.clear()
+        unet._graph.clear()
+        st = unet._plan("stream", kv)
+        st.cond_pl.run()
+        st.pl.run()
+        torch.cuda.synchronize()
+        st.pl.time_each_us(1)
+        us = st.pl.time_each_us(args.reps)
+        per = collections.defaultdict(list)
+        for j in range(len(st.pl)):
+            op = st.pl[j]
+            if op.kind == _lib.OP_WSGEMM:
+                per[(key_of(op), (op.i[9], op.i[10], op.i[11], max(1, op.i[12])))].append(us[j])
+        return {k: sum(v) / len(v) for k, v in per.items()}, {k: len(v) for k, v in per.items()}, sum(us)
+
+    ops._WS_TUNED.clear()                      # measure against the cost model, not against an older table
+    base, counts, frame0 = measure(None)
+    best = {k[0]: (t, k[1]) for k, t in base.items()}
+    default = dict(best)
+    lines = [f"default schedules: frame (sum of in-frame launch times) {frame0 / 1e3:.3f} ms"]
+    for nw, nt in ((1, 1), (2, 1), (4, 1), (5, 1), (8, 1), (2, 2), (4, 2)):
+        for S in (1, 2, 3, 4, 6, 8, 12):
+            for nl in (2, 1):
+                res, _c, fr = measure((nw, nt, nl, S))
+                for (key, sched), t in res.items():
+                    if sched != (nw, nt, nl, S):
+                        continue                 # (the forced schedule did not fit this shape: it ran with its default)
+                    if t < best[key][0]:
+                        best[key] = (t, sched)
+    table = {}
+    n_per_key = collections.Counter()
+    for (key, _s), c in counts.items():
+        n_per_key[key] += c
+    gain = 0.0
+    for key, (t, sched) in sorted(best.items()):
+        t0, s0 = default[key]
+        keep = t < 0.97 * t0
+        lines.append(f"{key:40s} x{n_per_key[key]:3d}  default {s0} {t0:6.1f} us   best {sched} {t:6.1f} us {'*' if keep else ''}")
+        if keep:
+            table[key] = list(sched)
+            gain += (t0 - t) * n_per_key[key]
+    lines.append(f"expected gain {gain / 1e3:.3f} ms per frame over the default schedules")
+    os.environ.pop("L2D_WSGEMM_FORCE", None)
+    old = {}
+    if os.path.exists(args.out):
+        old = json.load(open(args.out)).get("shapes", {})
+    old.update(table)
+    with open(args.out, "w") as f:
+        json.dump({"note": "in-frame picks of tools/wsgemm_tune.py: key = taps,M,Ktot,Nout,ntr,epi,pro -> [NW, NT, NL, S]", "shapes": old}, f, indent=1, sort_keys=True)
+    print("\n".join(lines))
+    if args.report:
+        open(args.report, "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
