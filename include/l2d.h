@@ -84,17 +84,18 @@ enum {
  *   p0 q [B][Tq][ldq] p1 k [B][Tk][ldk] p2 vt [B][H*d][ldvt] (V transposed) p3 out [B][Tq][ldo]
  *   i0 B i1 H i2 d i3 Tq i4 Tk i5 ldq i6 ldk i7 ldvt i8 ldo ; l0 q batch stride l1 k l2 vt l3 out
  *   p4 16-byte zero page (DMA source of keys beyond Tk; 0 selects the register-staged kernel)
- *   i9 variant: 0 auto (LDS-DMA ring kernel, flash_attn_ring.hip), 1 register-staged kernel, 2 / 3 ring kernel with
- *   32 / 16 query rows per wave, 4 / 5 further geometries (8 waves; 2-deep ring), 6 software-pipelined across key tiles
- *   (d <= 40; measured slower than 2, kept selectable for A/B).  V^T columns in [Tk, ldvt) may hold anything.
+ *   i9 variant: 0 auto (LDS-DMA ring kernel, flash_attn_ring.hip), 1 register-staged kernel (flash_attn.hip: the fallback for
+ *   K / V^T operands that are not 16-byte aligned), 2 / 3 ring kernel with 32 / 16 query rows per wave.  V^T columns in
+ *   [Tk, ldvt) may hold anything.
  *
  * L2D_OP_TATTN_STREAM  fused streaming temporal attention with multi-timestep KV-cache
  *                (reference stream_motion_module.py:99-213)
  *   p0 qkv [N*T][3C] half p1 cache [N,2,T,L,C] half (in-place) p2 q_pe p3 k_pe p4 v_pe [maxlen][C] half
  *   p5 pe_idx [N][L] int64 p6 update_idx [N] int64 p7 bias [N][L] half p8 out [N*T][C] half
  *   p9 16-byte zero page (DMA source of masked slots; required by the ring kernel, may be 0 otherwise)
- *   i0 N i1 T i2 C i3 L i4 H i5 variant (0 auto: LDS-DMA ring kernel for C in {320,640,1280}, L in {12,16},
- *   T % 8 == 0, else register-resident / chunked; 1 register-resident, 2/3 chunked CH=8/4, 13 ring: tuning knob)
+ *   i0 N i1 T i2 C i3 L i4 H i5 variant (0 auto: the loader-wave LDS-DMA ring kernel (tattn_ring.hip) for C in {320,640,1280},
+ *   L in {12,16,24,40}, T % 8 == 0, else register-resident (L <= 16) / chunked; 1 register-resident, 2/3 chunked CH=8/4,
+ *   13 = the ring kernel, refused when the shape does not fit it)
  *
  * L2D_OP_TATTN_WARMUP  bidirectional warm-up temporal attention + cache fill
  *                (reference motion_module.py:469-530)
@@ -150,14 +151,16 @@ enum {
  *   p0 x [M][ldx] half   p1 w half, packed in MFMA-fragment order [Nout/32][K/16][64 lanes][8] (ops.pack_rowgemm; GEGLU: rows
  *   permuted so that a 32-row tile holds 8 value / 8 gate / 8 value / 8 gate rows of 16 output channels)
  *   p2 bias float [Nout] (packed order) or 0   p3 residual [M][ldr] half or 0   p4 out [M][ldo] half
- *   p5 gamma / p6 beta half [K] of the prologue norm   p7 prologue 2: int64 [samples][G][2] fixed-point statistics of x
+ *   (the affine part of the prologue norm is folded into p1 / p2 at pack time: the kernel takes no gamma / beta; p5, p6 unused)
+ *   p7 prologue 2: int64 [samples][G][2] fixed-point statistics of x
  *   p8 outT half: output of the LAST i15 weight tiles, stored transposed [sample][channel][ldt] (V^T for the flash kernel)
  *   p9 / p10, i24..i29: GroupNorm statistics of the output for up to two consumers, exactly as L2D_OP_IGEMM
  *   i0 M i1 K i2 Nout (packed rows, % 32) i3 ldx i4 ldo i5 ldr i6 epi (0 none, 1 GEGLU: Nout / 2 output columns)
- *   i7 prologue (0 none, 1 LayerNorm over K, 2 GroupNorm apply) i8 activation after prologue 2 (0 none, 1 SiLU)
- *   i9 T tokens per sample (prologue 2, transposed output: T % (32 MT) == 0) i10 G groups of prologue 2
- *   i12 NW waves per block (1..10) i13 NT weight tiles per wave (1..4) i14 MT token tiles per block (1 | 2): a block
- *   computes 32 MT tokens x 32 NW NT packed rows; (Nout / 32) % (NW NT) == 0 (ops.rowgemm_schedule)
+ *   i7 prologue (0 none, 1 LayerNorm over K, 2 GroupNorm normalisation from p7)   (i8 unused)
+ *   i9 T tokens per sample (prologue 2, transposed output, output statistics: T % (32 MT) == 0) i10 G groups of prologue 2
+ *   i12 NW waves per block (1..8; 1..5 when NT >= 3) i13 NT weight tiles per wave (1..4) i14 MT token tiles per block
+ *   (1 | 2 | 4; MT >= 2 needs NT <= 2, MT = 4 needs K = 320): a block computes 32 MT tokens x 32 NW NT packed rows;
+ *   (Nout / 32) % (NW NT) == 0 (ops.rowgemm_schedule)
  *   i15 trailing weight tiles stored transposed to p8 (% (NW NT)) i16 ldt i17 block order (1 = weight-band major per XCD)
  *   l0 elements between samples in p8 ; f0 eps of the prologue norm
  *
@@ -169,6 +172,27 @@ enum {
  *   or 0   p6 out [M][ldo] half   p7 16-byte zero page   p9 / p10, i24..i29 GroupNorm statistics of the output as L2D_OP_IGEMM
  *   i1 C1 i2 C2 (both % 64) i3 ldx1 i4 ldx2 i5 CinP (= C1 + C2) i6 B i7 H i8 W i9 / i10 patch height / width (8x16, 8x8 or 4x8;
  *   H % PH == 0, W % PW == 0) i11 block order (1 = weight-tile major) i14 Nout (% 64) i15 ldo i16 ldr i17 ldrb i18 rows_per_bias
+ *
+ * L2D_OP_WSGEMM    weight-streaming GEMM for the levels with few tokens (M = N * T <~ 1k): linear layers and 3x3 stride-1 pad-1
+ *                convs with 128-token row tiles; every weight byte is fetched by one wave per row tile, straight into registers
+ *                (wsgemm.hip; reference: resnet.py:194,214 via InflatedConv3d :57-65; attention.py:173-205,258;
+ *                motion_module.py:360; stream_motion_module.py:99-147).  out[m][n] = epi( sum_k LN?(x)[m][k] * W[n][k] )
+ *   p0 x1 [M][ldx1] half (conv: [B,H,W,C1])   p1 x2 [M][ldx2] half or 0 (channel concat)   p2 w half, MFMA-fragment order
+ *   [Nout/32][taps*CinP/16][64 lanes][8] with k = tap * CinP + channel (ops.pack_wsgemm / pack_wsgemm_conv3x3; GEGLU rows permuted
+ *   as for L2D_OP_ROWGEMM)   p3 bias float [Nout] (packed order) or 0   p4 rowbias float [*][ldrb] or 0 (row = token / i18)
+ *   p5 residual [M][ldr] half or 0   p6 out [M][ldo] half   p7 zero region, >= 2 * CinP + 256 zero bytes (padding / ragged rows)
+ *   p8 outT half: output of the LAST i21 weight tiles, stored transposed [sample][channel][ldt] (V^T; T % 128 == 0)
+ *   p9 / p10, i24..i29 GroupNorm statistics of the output as L2D_OP_IGEMM (a tile may span samples: T % 32 == 0)
+ *   p11 split-K arrival counters (int32, one per (channel tile, row tile), zero before and after)   p12 split-K workspace float
+ *   [tiles][S][128 * 32 NW NT + 256]   p13 colsum float [Nout]: sum_k fp16(W'[n][k]) for the LayerNorm fold (i20 = 1)
+ *   i0 taps (1 | 9) i1 C1 i2 C2 (% 64) i3 ldx1 i4 ldx2 i5 CinP (= C1 + C2) i6 B i7 H i8 W (conv; W >= 8, M = B H W)
+ *   i9 NW consumer waves (1..8; 1..4 with NT = 2) i10 NT weight tiles per wave (1 | 2) i11 NL loader waves (1 | 2) i12 S K slices
+ *   (fused reduction: the last arriving block sums the S slabs in order 0..S-1 -- bit-repeatable -- and runs the epilogue)
+ *   i13 M i14 Nout (packed rows, % 32; (Nout / 32) % (NW NT) == 0) i15 ldo i16 ldr i17 ldrb i18 rows_per_bias (% 32)
+ *   i19 epi (0 none, 1 GEGLU: Nout / 2 output columns) i20 pro (0 none, 1 LayerNorm over K folded: gamma / beta live in p2 / p3,
+ *   out = rstd (acc - mean colsum) + bias with the row statistics taken in the kernel) i21 trailing weight tiles stored transposed
+ *   i22 ldt i23 non-temporal weight loads (single row tile) i30 T tokens per sample (p8)   l0 elements between samples in p8
+ *   f0 eps of the LayerNorm
  */
 enum {
     L2D_OP_IGEMM = 1,

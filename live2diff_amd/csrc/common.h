@@ -21,6 +21,15 @@ int l2d_check_launch(const char *what, int tag);
 extern int l2d_g_dry_run;
 #define L2D_DRY_RETURN() do { if (l2d_g_dry_run) return L2D_OK; } while (0)
 
+// > 64 KB of dynamic LDS must be opted into per kernel AND per device: launchers keep one flag per device ordinal
+// (`static bool done[L2D_MAX_DEV]`; a process that drives several GPUs sets the attribute on each of them)
+#define L2D_MAX_DEV 16
+static inline int l2d_dev_ordinal() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= L2D_MAX_DEV) return 0;
+    return dev;
+}
+
 // per-kernel launchers (one translation unit each); all return L2D_OK / L2D_E*
 int l2d_launch_igemm(const l2d_op *op, hipStream_t s);
 int l2d_launch_gn_stats(const l2d_op *op, hipStream_t s);

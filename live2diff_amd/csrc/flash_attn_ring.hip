@@ -459,7 +459,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(QS == 1
 template <int D, int QS, int NW, int NSF>
 static int launch_far_q(const FARArgs &a, hipStream_t s) {
     using Cf = FARCfg<D, NW, NSF>;
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (Cf::LDS > 65536 && !attr_done) {
         if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS, NW, NSF>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
             attr_done = true;

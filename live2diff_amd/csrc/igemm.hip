@@ -742,7 +742,8 @@ static void launch_v(const IGemmArgs &a, int batch, hipStream_t s) {
     constexpr size_t RING = (size_t)NS * (TN + TM) * BK * sizeof(h16);
     constexpr size_t EPI = (size_t)TM * (TN + 8) * sizeof(h16);        // the LDS-staged epilogue's transposed tile
     constexpr size_t LDS = RING > EPI ? RING : EPI;
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (LDS > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel
         // (fails inside a stream capture: the plan's first run is always direct -- HipStreamingUNet._run; if it fails
         // anyway the flag stays clear, the launch below reports the error and the next direct run retries)

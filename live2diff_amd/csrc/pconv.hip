@@ -267,7 +267,8 @@ static void launch_pc(const PConvArgs &a, hipStream_t s) {
     constexpr size_t RING = (size_t)2 * 8 * NPIXP * 16 + (size_t)3 * 64 * 64 * 2;
     constexpr size_t EPI = (size_t)(256 * 8 + 64) * 4;             // GroupNorm reduction scratch (the staged tile is smaller than the ring)
     constexpr size_t LDS = RING > EPI ? RING : EPI;
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (LDS > 65536 && !attr_done) {
         if (hipFuncSetAttribute((const void *)pconv_kernel<PH, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
         else (void)hipGetLastError();

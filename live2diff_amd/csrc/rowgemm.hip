@@ -525,7 +525,8 @@ __global__ __launch_bounds__(MAXT) void rowgemm_kernel(RowGemmArgs a) {
 
 template <int NT, int MT, int RD, int SK, int MAXT>
 static void launch_rg(const RowGemmArgs &a, int nthr, size_t lds, hipStream_t s) {
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (lds > 65536 && !attr_done) {   // > 64 KB of dynamic LDS must be opted into once per kernel (not inside a capture:
         // the plan's first run is always direct)
         if (hipFuncSetAttribute((const void *)rowgemm_kernel<NT, MT, RD, SK, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess)

@@ -509,7 +509,8 @@ static void launch_ringlw(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     constexpr int NT = 320;
     constexpr size_t LDS = (size_t)NS * R * 8 * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)tattn_stream_ringlw_kernel<HG, L, R, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;
@@ -529,7 +530,8 @@ static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     constexpr int NT = 40 * PB;
     constexpr size_t LDS = (size_t)NS * R * PB * 40 * 16 + (size_t)(NT * (L + 4) + L) * sizeof(float) + (size_t)2 * L * 320 * sizeof(h16);
     static_assert(LDS <= 160 * 1024, "tattn ring geometry exceeds the CU's LDS");
-    static bool attr_done = false;
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)tattn_stream_ring_kernel<HG, L, R, NS, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess)
             attr_done = true;

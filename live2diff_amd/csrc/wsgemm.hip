@@ -701,10 +701,9 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
 
 template <int NT, int RDS, int NL, bool NTW, int MAXW>
 static void launch_ws(const WsArgs &a, int nthr, size_t lds, hipStream_t s) {
-    static bool attr_done[16] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 65536 && dev >= 0 && dev < 16 && !attr_done[dev]) {   // > 64 KB of dynamic LDS: opted into once per kernel and device
+    static bool attr_done[L2D_MAX_DEV] = {false};
+    const int dev = l2d_dev_ordinal();
+    if (lds > 65536 && !attr_done[dev]) {   // > 64 KB of dynamic LDS: opted into once per kernel and device
         if (hipFuncSetAttribute((const void *)wsgemm_kernel<NT, RDS, NL, NTW, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess)
             attr_done[dev] = true;
         else

@@ -42,9 +42,13 @@ class SimilarImageFilter:
             self._kept.copy_(flat)
         self._kept_sq = (flat * flat).sum() if sq is None else sq
 
-    def similarity(self, x: torch.Tensor) -> float:
-        """cos(prev, x) with the reference's eps = 1e-6 clamp on each norm (torch.nn.CosineSimilarity semantics)."""
-        flat = x.detach().reshape(-1).float()
+    def similarity(self, x: torch.Tensor, flat: Optional[torch.Tensor] = None) -> float:
+        """cos(prev, x) with the reference's eps = 1e-6 clamp on each norm (torch.nn.CosineSimilarity semantics).  Deviation from the
+        reference, on purpose: the three reductions run in fp32 whatever the frame's dtype (the reference's CosineSimilarity
+        module computes in the input dtype, fp16 on the GPU); for frames within ~1e-3 of the threshold, where `skip_prob` is steep,
+        the two can decide differently.  The golden trace (tests/golden/frame_filter.json) pins the fp32 decisions."""
+        if flat is None:
+            flat = x.detach().reshape(-1).float()
         stats = torch.stack([(self._kept * flat).sum(), (flat * flat).sum(), self._kept_sq]).tolist()
         dot, xsq, psq = stats
         return dot / (max(psq ** 0.5, 1e-6) * max(xsq ** 0.5, 1e-6))
@@ -54,7 +58,7 @@ class SimilarImageFilter:
         if self._kept is None:
             self._remember(flat)
             return x
-        cos_sim = self.similarity(x)
+        cos_sim = self.similarity(x, flat)
         draw = self._rng.uniform(0, 1)
         skip_prob = 0.0 if self.threshold >= 1 else max(0.0, 1.0 - (1.0 - cos_sim) / (1.0 - self.threshold))
         if skip_prob < draw:                       # let it through and make it the new comparison frame

@@ -424,7 +424,7 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
     nch = Ktot // 64
     force = os.environ.get("L2D_WSGEMM_FORCE")        # "NW,NT,NL,S" (tools): applied where it divides the shape
     ntw = nm == 1
-    key = f"{taps},{M},{Ktot},{Nout},{ntr},{epi},{pro}"
+    key = wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro)
     cands = []
     for nt in (1, 2):
         for nw in range(1, (4 if nt == 2 else 8) + 1):
@@ -442,30 +442,27 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
         nw, nt, nl, S = _WS_TUNED[key][:4]
         if (nw, nt) in cands:
             return nw, nt, nl, max(1, min(S, nch)), ntw
-    cdiv = lambda a, b: (a + b - 1) // b
-    best, best_t = None, None
+    # default (shapes the table does not hold): two loader waves; about one block per CU (240-256 blocks); one weight tile per
+    # wave; the channel tile grows with the length of the contraction (a long K wants few, fat slices: the activation chunks are
+    # re-read by every channel tile) -- the pattern of the in-frame picks at cfg-2 (profiles/round4_a_wsgemm_tune_in_frame_cfg2.txt)
+    best, best_c = None, None
     for nw, nt in cands:
-        bn = 32 * nw * nt
-        ny = tiles // (nw * nt)
-        bpc = 2 if (nt == 1 and nw <= 4 and _ws_lds(nw, nt, epi, ntr, True) <= 81920) else 1
-        for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 16, 18, 20, 24, 30, 32, 36, 40, 45):
-            if S > nch or (S > 1 and (ntr or nch // S < 2)):
+        if nt != 1:
+            continue
+        ny = tiles // nw
+        for S in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+            if S > 1 and (ntr or nch // S < 4):
                 continue
             blocks = nm * ny * S
-            kc = cdiv(nch, S) * 64
-            rounds = cdiv(blocks, 256 * bpc)
-            conc = min(blocks, 256 * bpc)
-            # cycles per block: weight stream at the chip's HBM share (or L2 when another row tile already pulled the band),
-            # activations from L2 at ~25 B/clk/CU, MFMA pipe shared by the waves of a SIMD
-            hbm_share = 6.4e12 / 2.4e9 / max(1, min(conc, 256))          # B/clk for this block's weight stream
-            w_cyc = bn * kc * 2 / min(30.0, hbm_share * (nm if nm > 1 else 1))
-            x_cyc = WS_BM * kc * 2 / 25.0
-            m_cyc = nt * 4 * (kc / 16) * 32 * cdiv(nw * bpc, 4)
-            t = rounds * (max(w_cyc + x_cyc, m_cyc) + 6000)
-            if S > 1:
-                t += 2500 + S * WS_BM * bn * 4 / 40.0          # arrival + the last block's slab reads (~100 GB/s per block)
-            if best_t is None or t < best_t:
-                best, best_t = (nw, nt, 1, S, ntw), t
+            import math
+            c = abs(math.log(blocks / 248.0)) + 0.12 * math.log2(S) + (0.25 if blocks > 320 else 0.0)
+            want_bn = 32 if nch <= 24 else (64 if nch <= 96 else 128)       # K <= 1536: 32 channels per block, K <= 6144: 64, longer: 128
+            c += 0.2 * abs(math.log2(32 * nw / want_bn))
+            if best_c is None or c < best_c:
+                best, best_c = (nw, 1, 2, S, ntw), c
+    if best is None:
+        nw, nt = cands[0]
+        best = (nw, nt, 2, 1, ntw)
     return best
 
 
@@ -473,12 +470,23 @@ def _load_ws_tuned():
     import json
     path = os.path.join(os.path.dirname(__file__), "wsgemm_tuned.json")
     if os.environ.get("L2D_WSGEMM_NO_TABLE") or not os.path.exists(path):
-        return {}
+        return {}, set()
     with open(path) as f:
-        return json.load(f)["shapes"]
+        d = json.load(f)
+    return d["shapes"], set(d.get("skip", []))
 
 
-_WS_TUNED = _load_ws_tuned()
+_WS_TUNED, _WS_SKIP = _load_ws_tuned()
+
+
+def wsgemm_key(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0) -> str:
+    return f"{taps},{M},{Ktot},{Nout},{ntr},{epi},{pro}"
+
+
+def wsgemm_wanted(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0) -> bool:
+    """False for the shapes where the in-frame tuner measured the round-3 kernel (igemm / rowgemm) faster than the best wsgemm
+    schedule (`skip` list of wsgemm_tuned.json, tools/wsgemm_tune.py): the packer then keeps the old form for that layer."""
+    return wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro) not in _WS_SKIP
 
 
 def wsgemm_sizes(M: int, Nout: int, NW: int, NT: int, S: int):

@@ -19,6 +19,11 @@ import torch.distributed as dist
 def init_distributed(backend: Optional[str] = None, force: bool = False):
     """Initialise from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns (rank, world, local).
     `force`: create the process group even for world size 1 (exercises the backend's API surface on a single GPU)."""
+    # RCCL between processes shares device buffers through IPC handles; the host driver of these nodes supports dmabuf IPC only
+    # (without this the first collective fails with `hipIpcGetMemHandle: invalid argument`).  Must be in the environment before the
+    # HIP runtime of this process creates its first context, i.e. before the first torch.cuda call below -- ranks started by
+    # `torchrun` directly get it here, not only through bench.py's self-launcher.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))

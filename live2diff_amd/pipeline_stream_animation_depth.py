@@ -378,6 +378,8 @@ class StreamAnimateDiffusionDepth:
         self._pending = collections.deque()
 
     def push(self, x: Union[torch.Tensor, np.ndarray]) -> None:
+        if getattr(self, "_pending", None) is None:
+            raise RuntimeError("push() needs enable_frame_pipelining() first")
         cur = torch.cuda.current_stream()
         x = self.image_processor.preprocess(x, self.height, self.width).to(device=self.device, dtype=self.dtype)
         self._pre_stream.wait_stream(cur)                     # the frame is ready; earlier consumers of the side buffers are done
@@ -391,6 +393,10 @@ class StreamAnimateDiffusionDepth:
         self._pending.append((x_t_latent, depth_latent, ev))
 
     def pop(self) -> torch.Tensor:
+        """(The depth-path time of a popped frame is hidden under the previous frame's UNet step: `depth_time_ema` /
+        `depth_time_list` are not updated in this mode; `inference_time_ema` is.)"""
+        if getattr(self, "_pending", None) is None:
+            raise RuntimeError("pop() needs enable_frame_pipelining() first")
         if not self._pending:
             raise RuntimeError("pop() without a pushed frame")
         x_t_latent, depth_latent, ev = self._pending.popleft()
@@ -444,6 +450,10 @@ class StreamAnimateDiffusionDepth:
 
     @torch.no_grad()
     def __call__(self, x: Union[torch.Tensor, np.ndarray]) -> torch.Tensor:
+        if getattr(self, "_pending", None):
+            # the side stream may still be writing the static plan buffers this call would use (TAESD encoder, depth detector
+            # arena, glue scratch), and the host generator's draw order would change: finish the pushed frames first
+            raise RuntimeError("__call__ while pushed frames are pending: pop() them first (push / pop and __call__ share plan buffers)")
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         x = self.image_processor.preprocess(x, self.height, self.width).to(device=self.device, dtype=self.dtype)

@@ -120,8 +120,8 @@ class HipStreamingUNet:
         self.mm_layout = motion_module_layout(cfg, height, width)
         # levels whose stream batch is small enough for the weight-streaming GEMM (wsgemm.hip): N * T tokens <= L2D_WSGEMM_MAX_M and
         # samples made of whole 32-token tiles.  Decides the PACKING of those levels' layers (and with it the plan's kernels).
-        ws_on = os.environ.get("L2D_WSGEMM", "0") != "0"
-        ws_max = int(os.environ.get("L2D_WSGEMM_MAX_M", "512"))
+        ws_on = os.environ.get("L2D_WSGEMM", "1") != "0"             # A/B knob: 0 = the round-3 kernels everywhere
+        ws_max = int(os.environ.get("L2D_WSGEMM_MAX_M", "1280"))
         self.ws_levels = [ws_on and denoising_steps_num * (height >> l) * (width >> l) <= ws_max and ((height >> l) * (width >> l)) % 32 == 0
                           for l in range(cfg.num_levels)]
         if isinstance(state_dict, HipStreamingUNet):
@@ -176,10 +176,14 @@ class HipStreamingUNet:
             n, k = sd[wname].shape[0], sd[wname][0].numel()
             return use_rg and ops.rowgemm_ok(n, k)
 
-        def ws_ok(wname, lvl):
-            """the weight-streaming GEMM (wsgemm.hip) takes this layer: a level of few tokens, 32-row weight tiles, 64-column chunks"""
-            n, k = sd[wname].shape[0], sd[wname][0].numel()
-            return lvl is not None and ws_lv[lvl] and n % 32 == 0 and k % 64 == 0
+        def ws_ok(wname, lvl, n_mul=1, epi=0, pro=0, ntr=0, taps=1):
+            """the weight-streaming GEMM (wsgemm.hip) takes this layer: a level of few tokens, 32-row weight tiles, 64-column chunks,
+            and the in-frame tuner did not find the round-3 kernel faster for the shape (ops.wsgemm_wanted); n_mul: q | k | v"""
+            n, k = sd[wname].shape[0] * n_mul, sd[wname][0].numel()
+            if lvl is None or not ws_lv[lvl] or n % 32 or (k // taps) % 64:
+                return False
+            M_ = self.N * (self.h >> lvl) * (self.w >> lvl)
+            return ops.wsgemm_wanted(taps, M_, k, n, ntr, epi, pro)
 
         def lin(name, bias=True, norm=None, old=False, lvl=None, gnorm=False):
             """Linear layer `name`; `norm` = the LayerNorm (or, `gnorm`, GroupNorm) whose output feeds it.  At the few-token levels
@@ -187,7 +191,7 @@ class HipStreamingUNet:
             bias and column sums) -- except behind a GroupNorm, whose per-group scale cannot move to the accumulator side.
             Else token-row GEMM packing (rowgemm.hip: fragment order, the norm's affine folded into weight and bias) when the shape
             allows, else -- and with `old` in addition -- the implicit-GEMM packing with the norm applied by its own launch."""
-            if ws_ok(name + ".weight", lvl) and not gnorm:
+            if not gnorm and ws_ok(name + ".weight", lvl, pro=(1 if norm else 0)):
                 W[name + ".ww"], wb, wcs = ops.pack_wsgemm(g(name + ".weight"), g(name + ".bias") if bias else None,
                                                            g(norm + ".weight") if norm else None, g(norm + ".bias") if norm else None)
                 if wb is not None:
@@ -215,7 +219,7 @@ class HipStreamingUNet:
 
         def ff(name, norm, old=False, lvl=None):
             pw, pb = name + ".net.0.proj.weight", name + ".net.0.proj.bias"
-            if ws_ok(pw, lvl) and sd[pw].shape[0] % 256 == 0:          # (4 consumer waves x 32-row tiles behind the LayerNorm fold; GEGLU pairs)
+            if ws_ok(pw, lvl, epi=1, pro=1) and sd[pw].shape[0] % 64 == 0:
                 W[name + ".ww1"], W[name + ".wb1"], W[name + ".wcs1"] = ops.pack_wsgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"),
                                                                                          geglu=True)
                 lin(name + ".net.2", old=old, lvl=lvl)
@@ -241,7 +245,7 @@ class HipStreamingUNet:
         def conv3ws(name, lvl):
             """resnet 3x3 conv: weight-streaming packing at the few-token levels, else the implicit-GEMM / patch-conv packing"""
             cw = sd[name + ".weight"]
-            if ws_lv[lvl] and cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0:
+            if cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0 and ws_ok(name + ".weight", lvl, taps=9):
                 W[name + ".ww"] = ops.pack_wsgemm_conv3x3(g(name + ".weight"))
                 W[name + ".b"] = ops.f32(g(name + ".bias"))
             else:
@@ -273,7 +277,7 @@ class HipStreamingUNet:
             for n in ("norm1", "norm2", "norm3"):
                 norm(b + "." + n)
             wq, wk, wv = (g(b + f".attn1.to_{c}.weight") for c in "qkv")
-            if ws_ok(b + ".attn1.to_q.weight", lvl) and Tl % 128 == 0 and wq.shape[0] % 128 == 0:
+            if Tl % 128 == 0 and ws_ok(b + ".attn1.to_q.weight", lvl, n_mul=3, pro=1, ntr=wq.shape[0]):
                 # q | k | v in one weight-streaming launch behind norm1 (V leaves transposed: a sample is whole 128-token tiles)
                 W[b + ".attn1.qkv.ww"], W[b + ".attn1.qkv.wb"], W[b + ".attn1.qkv.wcs"] = ops.pack_wsgemm(
                     torch.cat([wq, wk, wv], 0), None, g(b + ".norm1.weight"), g(b + ".norm1.bias"))
@@ -285,7 +289,7 @@ class HipStreamingUNet:
                 W[b + ".attn1.qk"] = ops.pack_linear(torch.cat([wq, wk], 0))
                 W[b + ".attn1.v"] = ops.pack_linear(wv)
             lin(b + ".attn1.to_out.0", old=old, lvl=lvl)
-            lin(b + ".attn2.to_q", bias=False, norm=b + ".norm2", old=old, lvl=(lvl if wq.shape[0] % 128 == 0 else None))
+            lin(b + ".attn2.to_q", bias=False, norm=b + ".norm2", old=old, lvl=lvl)
             self.text_offsets[name] = sum(t.shape[0] for t in text_k)
             text_k.append(g(b + ".attn2.to_k.weight").to(torch.float16))
             text_v.append(g(b + ".attn2.to_v.weight").to(torch.float16))
@@ -306,7 +310,7 @@ class HipStreamingUNet:
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
                 wq, wk, wv = g(a + ".to_q.weight"), g(a + ".to_k.weight"), g(a + ".to_v.weight")
-                if ws_ok(a + ".to_q.weight", lvl) and (3 * wq.shape[0]) % 128 == 0:
+                if ws_ok(a + ".to_q.weight", lvl, n_mul=3, pro=1):
                     W[a + ".qkv.ww"], W[a + ".qkv.wb"], W[a + ".qkv.wcs"] = ops.pack_wsgemm(
                         torch.cat([wq, wk, wv], 0), None, g(b + f".norms.{j}.weight"), g(b + f".norms.{j}.bias"))
                 elif rg_ok(a + ".to_q.weight"):
@@ -366,21 +370,24 @@ class HipStreamingUNet:
         return sum(t.numel() * t.element_size() for t in self.W.values())
 
     # ------------------------------------------------------------------ packed-weight cache
-    PACK_FORMAT = 2      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
+    PACK_FORMAT = 3      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
 
     def save_packed(self, path) -> None:
         """Write the packed weights (what `_pack_weights` produced from the reference-keyed state dict: merged
         DreamBooth / LoRA weights, permuted, fused and padded for the kernels, PE tables pre-projected) as one
         safetensors file.  The analogue of the reference's TensorRT engine cache (wrapper.py:300-332, :505-560): a style
-        switch that was seen before skips the conversion.  Packed weights depend on the weights and on the window
-        length only -- not on resolution or on the number of denoising steps."""
+        switch that was seen before skips the conversion.  Packed weights depend on the weights, on the window length and on
+        WHICH KERNEL serves each layer: the levels with few stream tokens (`ws_levels`: denoising steps x latent size) hold the
+        weight-streaming forms, levels whose samples are not whole 32-token tiles the implicit-GEMM forms, and the L2D_ROWGEMM*
+        knobs move layers between kernels.  The file records all of that; `_load_packed` refuses a file packed for another layout
+        with a "re-pack" error instead of failing on a missing tensor later."""
         import json
 
         from safetensors.torch import save_file
         meta = dict(format=str(self.PACK_FORMAT), abi=str(_lib.ABI_VERSION), window=str(self.cfg.window_size),
                     block_out_channels=json.dumps(list(self.cfg.block_out_channels)),
                     temb_offsets=json.dumps(self.temb_offsets), text_offsets=json.dumps(self.text_offsets),
-                    n_map_blocks=str(self.n_map_blocks))
+                    n_map_blocks=str(self.n_map_blocks), layout=json.dumps(self._pack_layout()))
         save_file({k: v.detach().cpu().contiguous() for k, v in self.W.items()}, str(path), metadata=meta)
 
     def _load_packed(self, path) -> None:
@@ -392,6 +399,9 @@ class HipStreamingUNet:
             if int(meta.get("format", -1)) != self.PACK_FORMAT or int(meta.get("abi", -1)) != _lib.ABI_VERSION:
                 raise ValueError(f"{path}: packed-weight format {meta.get('format')} / ABI {meta.get('abi')} does not match "
                                  f"this build ({self.PACK_FORMAT} / {_lib.ABI_VERSION}): re-pack from the state dict")
+            if json.loads(meta.get("layout", "null")) != self._pack_layout():
+                raise ValueError(f"{path}: packed for kernel layout {meta.get('layout')}, this instance needs {json.dumps(self._pack_layout())} "
+                                 "(latent size / denoising steps / L2D_ROWGEMM* / L2D_WSGEMM* differ): re-pack from the state dict")
             if int(meta["window"]) != self.cfg.window_size or json.loads(meta["block_out_channels"]) != list(self.cfg.block_out_channels):
                 raise ValueError(f"{path}: packed for window {meta['window']} / widths {meta['block_out_channels']}, "
                                  f"this instance is window {self.cfg.window_size} / {list(self.cfg.block_out_channels)}")
@@ -402,14 +412,26 @@ class HipStreamingUNet:
         self.temb_total = self.W["temb_all.w"].shape[0]
         self.text_total, self.text_kp = self.W["text_k.w"].shape
 
+    def _pack_layout(self) -> dict:
+        """what decides which packed form each layer has (besides the weights themselves)"""
+        nl = self.cfg.num_levels
+        return dict(ws_levels=[bool(v) for v in self.ws_levels],
+                    old_levels=[((self.h >> l) * (self.w >> l)) % 32 != 0 for l in range(nl)],
+                    ws_skip=sorted(ops._WS_SKIP), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
+                    rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
+                    rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))
+
     @staticmethod
-    def packed_cache_name(model_name: str, few_step_model_type: str, window_size: int, lora_dict: Optional[dict] = None) -> str:
-        """File stem for a packed-weight cache entry, in the spirit of the reference's engine prefix
-        (wrapper.py:300-332) minus what packed weights do not depend on (steps, resolution, tiny-VAE)."""
+    def packed_cache_name(model_name: str, few_step_model_type: str, window_size: int, lora_dict: Optional[dict] = None,
+                          height: int = 0, width: int = 0, denoising_steps_num: int = 0) -> str:
+        """File stem for a packed-weight cache entry, in the spirit of the reference's engine prefix (wrapper.py:300-332).  Since
+        round 4 the packed forms depend on the stream shape (which levels take the weight-streaming kernel), so the LATENT size
+        and the number of denoising steps are part of the name like they are in the reference's prefix; the tiny-VAE is not."""
         stem = f"{model_name}--{few_step_model_type}--"
         for k, v in (lora_dict or {}).items():
             stem += f"{os.path.splitext(os.path.basename(str(k)))[0]}-{v}--"
-        return stem + f"L{window_size}--l2dpack{HipStreamingUNet.PACK_FORMAT}"
+        shape = f"{height}x{width}x{denoising_steps_num}--" if height and width and denoising_steps_num else ""
+        return stem + shape + f"L{window_size}--l2dpack{HipStreamingUNet.PACK_FORMAT}"
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, mode: str, kv_cache: List[torch.Tensor]):

@@ -112,7 +112,7 @@ def hf_forward(sd, x, img):
 
 
 def main():
-    from live2diff_amd.midas_hip import random_midas_state_dict
+    from live2diff_amd.midas_spec import random_midas_state_dict      # (plain torch: no HIP library needed)
     out = {}
     for img, B in ((128, 2), (384, 1)):
         sd = random_midas_state_dict(dtype=torch.float32, img=img)

@@ -244,20 +244,29 @@ def test_packed_weight_cache_round_trip(dry_run, tmp_path):
     from live2diff_amd.weights import random_state_dict
     cfg = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
     a = HipStreamingUNet(random_state_dict(cfg, dtype=torch.float16), cfg, 16, 16, 2, device="cpu")
-    path = tmp_path / (HipStreamingUNet.packed_cache_name("sd15", "lcm", cfg.window_size, {"loras/style.safetensors": 0.8}) + ".safetensors")
-    assert path.name == f"sd15--lcm--style-0.8--L{cfg.window_size}--l2dpack2.safetensors"
+    path = tmp_path / (HipStreamingUNet.packed_cache_name("sd15", "lcm", cfg.window_size, {"loras/style.safetensors": 0.8}, 16, 16, 2) + ".safetensors")
+    assert path.name == f"sd15--lcm--style-0.8--16x16x2--L{cfg.window_size}--l2dpack3.safetensors"
     a.save_packed(path)
-    b = HipStreamingUNet(path, cfg, 16, 32, 3, device="cpu")          # other resolution / step count: same packed weights
+    b = HipStreamingUNet(path, cfg, 16, 16, 2, device="cpu")
     assert set(a.W) == set(b.W) and all(torch.equal(a.W[k], b.W[k]) and a.W[k].dtype == b.W[k].dtype for k in a.W)
     assert a.temb_offsets == b.temb_offsets and a.text_offsets == b.text_offsets
     assert (a.temb_total, a.text_total, a.text_kp, a.n_map_blocks) == (b.temb_total, b.text_total, b.text_kp, b.n_map_blocks)
-    b._plan("stream", b.prepare_cache(3)).pl.run(stream=0)             # validate-only
+    b._plan("stream", b.prepare_cache(2)).pl.run(stream=0)             # validate-only
     with pytest.raises(ValueError):
         HipStreamingUNet(path, tiny_config(window_size=24, channels=(64, 128, 128, 128), cross_attention_dim=64), 16, 16, 2, device="cpu")
-    # a resolution whose token counts need the implicit-GEMM form of a level the file was not packed for: refused by name
-    c = HipStreamingUNet(path, cfg, 8, 24, 2, device="cpu")
+    # which kernel serves a layer depends on the stream shape (levels with few tokens: weight-streaming forms; samples that are not
+    # whole 32-token tiles: implicit-GEMM forms): a file packed for another layout is refused when it is LOADED, by name
     with pytest.raises(ValueError, match="re-pack"):
-        c._plan("stream", c.prepare_cache(2))
+        HipStreamingUNet(path, cfg, 16, 32, 3, device="cpu")
+    with pytest.raises(ValueError, match="re-pack"):
+        HipStreamingUNet(path, cfg, 8, 24, 2, device="cpu")
+    # ... and a shape change that leaves the layout alone reuses the file (the same levels take the same kernels)
+    big = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    a2 = HipStreamingUNet(random_state_dict(big, dtype=torch.float16), big, 64, 64, 2, device="cpu")
+    p2 = tmp_path / "big.safetensors"
+    a2.save_packed(p2)
+    if a2._pack_layout() == HipStreamingUNet(a2, big, 64, 64, 2, device="cpu")._pack_layout():
+        HipStreamingUNet(p2, big, 64, 64, 2, device="cpu")
 
 
 def test_plan_algorithmic_work_matches_survey(dry_run):

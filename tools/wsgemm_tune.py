@@ -65,6 +65,26 @@ def main():
         return {k: sum(v) / len(v) for k, v in per.items()}, {k: len(v) for k, v in per.items()}, sum(us)
 
     ops._WS_TUNED.clear()                      # measure against the cost model, not against an older table
+    ops._WS_SKIP.clear()
+    # ---- the round-3 kernels on the same layers (a second instance packed without wsgemm): in-frame time per shape key
+    os.environ["L2D_WSGEMM"] = "0"
+    unet0 = HipStreamingUNet(device_random_state_dict(cfg, dev), cfg, h, w, N, device=dev)
+    os.environ["L2D_WSGEMM"] = "1"
+    st0 = unet0._plan("stream", kv)
+    st0.cond_pl.run(); st0.pl.run()
+    torch.cuda.synchronize()
+    st0.pl.time_each_us(1)
+    us0 = st0.pl.time_each_us(args.reps)
+    old = collections.defaultdict(list)
+    for j in range(len(st0.pl)):
+        op = st0.pl[j]
+        i = op.i
+        if op.kind == _lib.OP_IGEMM and max(1, i[20]) == 1 and i[11] == 1 and i[12] == 0:
+            old[ops.wsgemm_key(i[0], i[13], i[0] * (i[1] + i[2]), i[14], 0, 1 if i[19] == 1 else 0, 0)].append(us0[j])
+        elif op.kind == _lib.OP_ROWGEMM and i[7] != 2:
+            old[ops.wsgemm_key(1, i[0], i[1], i[2], i[15] * 32, i[6], i[7])].append(us0[j])
+    old = {k: sum(v) / len(v) for k, v in old.items()}
+    del unet0, st0
     base, counts, frame0 = measure(None)
     best = {k[0]: (t, k[1]) for k, t in base.items()}
     default = dict(best)
@@ -78,7 +98,7 @@ def main():
                         continue                 # (the forced schedule did not fit this shape: it ran with its default)
                     if t < best[key][0]:
                         best[key] = (t, sched)
-    table = {}
+    table, skip = {}, []
     n_per_key = collections.Counter()
     for (key, _s), c in counts.items():
         n_per_key[key] += c
@@ -86,18 +106,28 @@ def main():
     for key, (t, sched) in sorted(best.items()):
         t0, s0 = default[key]
         keep = t < 0.97 * t0
-        lines.append(f"{key:40s} x{n_per_key[key]:3d}  default {s0} {t0:6.1f} us   best {sched} {t:6.1f} us {'*' if keep else ''}")
+        t_old = old.get(key)
+        worse = t_old is not None and t_old < 0.97 * t
+        lines.append(f"{key:40s} x{n_per_key[key]:3d}  default {s0} {t0:6.1f} us   best {sched} {t:6.1f} us {'*' if keep else ' '}"
+                     f"   round-3 kernel {t_old if t_old is not None else float('nan'):6.1f} us {'-> skip' if worse else ''}")
+        if worse:
+            skip.append(key)
         if keep:
             table[key] = list(sched)
             gain += (t0 - t) * n_per_key[key]
     lines.append(f"expected gain {gain / 1e3:.3f} ms per frame over the default schedules")
     os.environ.pop("L2D_WSGEMM_FORCE", None)
-    old = {}
+    prev, prev_skip = {}, []
     if os.path.exists(args.out):
-        old = json.load(open(args.out)).get("shapes", {})
-    old.update(table)
+        d_ = json.load(open(args.out))
+        prev, prev_skip = d_.get("shapes", {}), d_.get("skip", [])
+    prev.update(table)
+    measured = set(best)
+    prev_skip = sorted((set(prev_skip) - measured) | set(skip))
     with open(args.out, "w") as f:
-        json.dump({"note": "in-frame picks of tools/wsgemm_tune.py: key = taps,M,Ktot,Nout,ntr,epi,pro -> [NW, NT, NL, S]", "shapes": old}, f, indent=1, sort_keys=True)
+        json.dump({"note": "in-frame picks of tools/wsgemm_tune.py: key = taps,M,Ktot,Nout,ntr,epi,pro -> [NW, NT, NL, S]; skip = shapes "
+                           "where the round-3 kernel (igemm / rowgemm) measured >= 3 % faster in the frame: the packer keeps its form",
+                   "shapes": prev, "skip": prev_skip}, f, indent=1, sort_keys=True)
     print("\n".join(lines))
     if args.report:
         open(args.report, "w").write("\n".join(lines) + "\n")
