@@ -611,7 +611,7 @@ def main():
                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                                   "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
                                   "note": "dominant kernel family by time; the figure comparable with the single igemm family of rounds 1-2 "
-                                          "is roofline_gemm_kernels (igemm + rowgemm + pconv)"}
+                                          "is roofline_gemm_kernels (igemm + rowgemm + pconv + wsgemm)"}
         else:
             ach = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9
             result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
@@ -619,13 +619,45 @@ def main():
         my_frac = result["roofline"]["frac"]
         # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
         # rate is the figure comparable with the single igemm family of rounds 1-2
-        gem = [rows[k_] for k_ in ("igemm_kernel", "rowgemm_kernel", "pconv_kernel") if k_ in rows]
+        GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel")
+        gem = [rows[k_] for k_ in GEMM_FAMILIES if k_ in rows]
         if gem:
             gms, gfl = sum(g_["ms"] for g_ in gem), sum(g_["flops"] for g_ in gem)
-            result["roofline_gemm_kernels"] = {"kernels": [k_ for k_ in ("igemm_kernel", "rowgemm_kernel", "pconv_kernel") if k_ in rows],
+            result["roofline_gemm_kernels"] = {"kernels": [k_ for k_ in GEMM_FAMILIES if k_ in rows],
                                                "bound": "mfma", "launches": sum(g_["launches"] for g_ in gem), "ms_per_frame": round(gms, 4),
                                                "achieved": round(gfl / (gms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                "frac": round(gfl / (gms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        # the decode-shaped half of the network (levels with M = N * T <= 512 tokens: weight-streaming problems, priced against the
+        # HBM roofline): sum of algorithmic bytes of those GEMM launches / their time, replayed back to back (cold weights: every
+        # launch has its own)
+        try:
+            import ctypes as _ct
+            from live2diff_amd import _lib as _l
+            st_ = unet._plans["stream"]
+            small = []
+            for j_ in range(len(st_.pl)):
+                o_ = st_.pl[j_]
+                m_ = {_l.OP_IGEMM: o_.i[13], _l.OP_ROWGEMM: o_.i[0], _l.OP_WSGEMM: o_.i[13]}.get(o_.kind)
+                if m_ is not None and 0 < m_ <= 512:
+                    small.append(o_)
+            if small:
+                pl_ = _l.OpList()
+                for o_ in small:
+                    c_ = _l.L2dOp()
+                    _ct.memmove(_ct.byref(c_), _ct.byref(o_), _ct.sizeof(_l.L2dOp))
+                    pl_.append(c_)
+                pl_.time_ms(1)
+                ms_ = pl_.time_ms(5)
+                by_ = sum(op_work(o_, _l)[1] for o_ in small)
+                fl_ = sum(op_work(o_, _l)[0] for o_ in small)
+                result["roofline_small_m"] = {"what": "GEMM launches with M <= 512 tokens (levels 2 / 3 / mid at cfg-2)", "bound": "hbm",
+                                              "launches": len(small), "ms_per_frame": round(ms_, 4), "algorithmic_bytes": round(by_),
+                                              "achieved": round(by_ / (ms_ * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                              "frac": round(by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                              "tflops": round(fl_ / (ms_ * 1e-3) / 1e12, 1),
+                                              "kernels": sorted({KIND_NAMES.get(o_.kind, str(o_.kind)) for o_ in small})}
+        except Exception as e_:          # noqa: BLE001  (informational leg)
+            result["roofline_small_m"] = {"error": str(e_)[:200]}
         # the HBM-bound streaming KV-cache kernel is the one north_star singles out: always report it too
         t = rows.get("tattn_stream_kernel")
         if t:

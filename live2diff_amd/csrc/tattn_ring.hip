@@ -69,8 +69,10 @@ __device__ __forceinline__ void ring_axpy8(float (&o)[8], float p, h16x8 v) {
     }
 }
 
-// Round-2 form, kept as the A/B partner of the loader-wave kernels below (L2D_TATTN_RING=4) and as the carrier of the
-// in-kernel stage stamps (tools/tattn_probe.py): every one of the five waves issues its own share of a stage's refill and then
+#ifdef L2D_PROBES
+// Round-2 form: ANALYSIS BUILDS ONLY (make PROBES=1; L2D_TATTN_RING=4 selects it there) -- the A/B partner of the loader-wave
+// kernel below and the carrier of the in-kernel stage stamps (tools/tattn_probe.py); the product library does not contain it
+// (round 4).  Every one of the five waves issues its own share of a stage's refill and then
 // does the stage's arithmetic.  HG = threads per head (d / 8): 5, 10, 20.  R cache rows per ring stage, NS stages: (4, 5) =
 // 100 KB of ring, one block of PB = 8 pixels x 40 threads per CU.  Geometries that were measured and removed again (round 2 /
 // round 3, profiles/r2l*, round3_e_*): (2 rows, 3 stages) with two blocks per CU (10 % slower), 16-pixel / 10-wave blocks (equal),
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(40 * PB) void tattn_stream_ring_kernel(TAttnArgs a,
         l2d_st8(out_b + (long long)gi * (PB * C) + ooff, ov);
     }
 }
+#endif
 
 // Loader-wave form (round 3, the default).  In the kernel above every wave issues its share of a stage's refill (4
 // `global_load_lds`, ~200 cycles of issue EACH in this kernel) and then does the stage's arithmetic: a stage is the sum of
@@ -525,6 +528,7 @@ static void launch_ringlw(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     hipLaunchKernelGGL((tattn_stream_ringlw_kernel<HG, L, R, NS>), dim3(a.N * CH * bpu), dim3(384), LDS, s, a, zero, gpb, groups_per_unit);
 }
 
+#ifdef L2D_PROBES
 template <int L, int HG, int R, int NS, int PB>
 static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStream_t s) {
     constexpr int NT = 40 * PB;
@@ -545,22 +549,25 @@ static void launch_ring_g(const TAttnArgs &a, const h16 *zero, int slots, hipStr
     const int bpu = (groups_per_unit + gpb - 1) / gpb;
     hipLaunchKernelGGL((tattn_stream_ring_kernel<HG, L, R, NS, PB>), dim3(a.N * CH * bpu), dim3(NT), LDS, s, a, zero, gpb, groups_per_unit);
 }
+#endif
 
 template <int L, int HG>
 static void launch_ring(const TAttnArgs &a, const h16 *zero, int cus, hipStream_t s) {
-    // L2D_TATTN_RING=4: the round-2 form (every wave issues its own DMAs; L <= 24), for A/B; default: the loader-wave kernel
+#ifdef L2D_PROBES
+    // analysis builds: L2D_TATTN_RING=4 = the round-2 form (every wave issues its own DMAs; L <= 24), for A/B and stage stamps
     static int geo = -2;
     if (geo == -2) {
         const char *e = getenv("L2D_TATTN_RING");
         geo = e ? atoi(e) : -1;
     }
+    if constexpr (L <= 16) { if (geo == 4) { launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s); return; } }
+    else if constexpr (L == 24) { if (geo == 4) { launch_ring_g<L, HG, 4, 4, 8>(a, zero, cus, s); return; } }
+#endif
     if constexpr (L <= 16) {
-        if (geo == 4) launch_ring_g<L, HG, 4, 5, 8>(a, zero, cus, s);
-        else launch_ringlw<L, HG, 4, 5>(a, zero, cus, s);
+        launch_ringlw<L, HG, 4, 5>(a, zero, cus, s);
     } else if constexpr (L == 24) {
         // 24 slots: PE rows 2 x 15 KB + score rows 35 KB leave room for 4 stages of 4 rows ((2 rows, 8 stages): 3 % slower)
-        if (geo == 4) launch_ring_g<L, HG, 4, 4, 8>(a, zero, cus, s);
-        else launch_ringlw<L, HG, 4, 4>(a, zero, cus, s);
+        launch_ringlw<L, HG, 4, 4>(a, zero, cus, s);
     } else {
         launch_ringlw<L, HG, 2, 5>(a, zero, cus, s);
     }

@@ -205,19 +205,23 @@ def test_sd15_width_other_baseline_configs(golden, sd15_weights, name, h, w, N, 
     _assert(report)
 
 
-def test_cfg2_full_size_frame_against_oracle(sd15_weights):
-    """BASELINE configs[1] at FULL size (64x64 latent, N = 2, L = 16, SD-1.5 widths, 3.04 GB of KV cache): two streaming
-    frames on pre-filled N(0,1) caches with the steady-state ring buffer, against the fp32 oracle on the same weights,
-    inputs and caches (the oracle needs ~7 s per frame on 32 host threads, bench.py `cpu_baseline`).  Checks the
-    eps-prediction of both frames and, in every one of the 40 caches, the slot the frame wrote."""
+@pytest.mark.parametrize("name,h,w,N,L,S", [
+    ("cfg-2: 512x512, N = 2, L = 16 (3.04 GB of KV cache)", 64, 64, 2, 16, 8),
+    ("cfg-3: 768x512, N = 2, L = 24 (6.84 GB)", 64, 96, 2, 24, 8),
+    ("cfg-5: 1024x576, N = 2, L = 40 (17.1 GB)", 72, 128, 2, 40, 8),
+])
+def test_full_size_frame_against_oracle(sd15_weights, name, h, w, N, L, S):
+    """BASELINE configs[1], [2] and [4] at FULL size (SD-1.5 widths, the latent, window and cache sizes the numbers are quoted
+    on): two streaming frames on pre-filled N(0,1) caches with the steady-state ring buffer, against the fp32 oracle on the same
+    weights, inputs and caches (the oracle needs ~7 / ~11 / ~30 s per frame on 32 host threads, bench.py `cpu_baseline`).
+    Checks the eps-prediction of both frames and, in every one of the 40 caches, the slot the frame wrote."""
     from live2diff_amd.config import sd15_config
     from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init, ring_buffer_update
     from live2diff_amd.unet_hip import HipStreamingUNet
     from oracle import unet_ref as O
     import os
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    cfg = sd15_config()
-    N, h, w = 2, 64, 64
+    cfg = sd15_config(window_size=L, sink_size=S)
     sd, sd32 = sd15_weights
     unet = HipStreamingUNet({k: v.to(DEV) for k, v in sd.items()}, cfg, h, w, N)
     g = torch.Generator().manual_seed(4321)

@@ -305,8 +305,11 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     n, fl, by = tot[_lib.OP_TATTN_STREAM]
     assert n == 40 and abs(by - (kv_bytes + 2 * kv_bytes / cfg.window_size)) < 1e-6 * by   # K+V once + (row write, q, out) = 8 N T C bytes
     # 380 GEMM launches in round 2; the 16 V^T projections now ride in the q | k | V^T row GEMMs
-    gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV)]      # (21 level-0 / level-1 3x3 convs: patch kernel)
+    # (21 level-0 / level-1 3x3 convs: patch kernel; the levels with <= 512 stream tokens: weight-streaming GEMM where the in-frame
+    #  tuner found it faster, round 4)
+    gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV, _lib.OP_WSGEMM) if k_ in tot]
     assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 and tot[_lib.OP_PCONV][0] == 21
+    assert tot.get(_lib.OP_WSGEMM, [0])[0] >= 50
     assert abs(sum(g_[1] for g_ in gemm) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
     assert _lib.OP_LAYERNORM not in tot
 
@@ -472,3 +475,61 @@ def test_unet_instances_can_share_packed_weights(dry_run):
         HipStreamingUNet(u, cfg, 8, 8, 2, device="cpu")
     with pytest.raises(ValueError):
         HipStreamingUNet(u, tiny_config(window_size=12, sink_size=4), 16, 16, 2, device="cpu")
+
+
+def test_wsgemm_packers_schedule_and_validation(dry_run):
+    """Host side of the weight-streaming GEMM (csrc/wsgemm.hip) without a GPU: the fragment packing is a permutation that
+    rowgemm's inverse undoes, the LayerNorm fold's column sums are the row sums of the ROUNDED folded weights, the conv packing
+    orders k as (tap, channel), every default / tuned schedule passes the library's argument validation for the frame's shapes,
+    and malformed launches are refused."""
+    from live2diff_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(96, 128, generator=g)
+    b, gm, bt = torch.randn(96, generator=g), 1 + 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+    wp, bp, cs = ops.pack_wsgemm(w, b, gm.half(), bt.half())
+    wf = (w * gm.half().float()[None]).half()
+    assert torch.equal(ops.unpack_rowgemm(wp, 96, 128), wf)                          # same fragment order as rowgemm
+    assert torch.allclose(cs, wf.float().sum(1)) and torch.allclose(bp, b + w @ bt.half().float(), atol=1e-5)
+    assert ops.pack_wsgemm(w, b)[2] is None
+    cw = torch.randn(64, 70, 3, 3, generator=g)
+    cp = ops.pack_wsgemm_conv3x3(cw)
+    flat = ops.unpack_rowgemm(cp, 64, 9 * 128).view(64, 9, 128)
+    assert torch.equal(flat[:, :, :70], cw.permute(0, 2, 3, 1).reshape(64, 9, 70).half()) and (flat[:, :, 70:] == 0).all()
+
+    def validate(opk):
+        pl = _lib.OpList()
+        pl.append(*opk)
+        pl.run(stream=0)
+
+    cnt = torch.zeros(4096, dtype=torch.int32)
+    for (taps, M, C1, C2, N, epi, pro, ntr) in ((1, 512, 1280, 0, 1280, 0, 0, 0), (1, 128, 1280, 0, 10240, 1, 1, 0), (1, 512, 1280, 0, 3840, 0, 1, 1280),
+                                                 (1, 768, 5120, 0, 1280, 0, 0, 0), (9, 128, 1280, 1280, 1280, 0, 0, 0), (9, 1152, 640, 0, 1280, 0, 0, 0),
+                                                 (1, 192, 1280, 1280, 1280, 0, 0, 0), (1, 300, 64, 0, 96, 0, 0, 0)):
+        K = C1 + C2
+        sched = ops.wsgemm_schedule(M, taps * K, N, ntr, epi, pro, taps)
+        NW, NT, NL, S, ntw = sched
+        assert (N // 32) % (NW * NT) == 0 and (ntr // 32) % (NW * NT) == 0 and 1 <= S <= taps * K // 64
+        x1, x2 = torch.zeros(M, C1, dtype=torch.float16), (torch.zeros(M, C2, dtype=torch.float16) if C2 else None)
+        wt = torch.zeros(N * taps * K, dtype=torch.float16)
+        No = N // 2 if epi else N
+        kw = {}
+        if S > 1:
+            n_ws, n_cnt = ops.wsgemm_sizes(M, N, NW, NT, S)
+            kw = dict(ws=torch.zeros(n_ws), cnt=cnt)
+        T = M // 2 if ntr == 0 else 256
+        HW = {128: (8, 8), 1152: (18, 32)}.get(M, (1, 1))
+        out_t = torch.zeros(M // T, ntr, T + 8, dtype=torch.float16) if ntr else None
+        validate(ops.wsgemm(x1, wt, torch.zeros(M, (N - ntr) // (2 if epi else 1) or No, dtype=torch.float16), M=M, Nout=N, C1=C1, ldx1=C1, x2=x2, C2=C2,
+                            ldx2=C2, ldo=(N - ntr) // (2 if epi else 1), bias=torch.zeros(N), colsum=(torch.zeros(N) if pro else None), taps=taps,
+                            B=2, H=HW[0], W=HW[1], epi=epi, pro=pro, T=T, out_t=out_t, ntr=ntr, ldt=T + 8, st=ntr * (T + 8), sched=sched, **kw))
+    x, wt, out = torch.zeros(128, 64, dtype=torch.float16), torch.zeros(64 * 64, dtype=torch.float16), torch.zeros(128, 64, dtype=torch.float16)
+    with pytest.raises(_lib.L2DError):
+        validate(ops.wsgemm(x, wt, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(3, 1, 1, 1, False)))     # 2 tiles over 3 waves
+    with pytest.raises(_lib.L2DError):
+        op, keep = ops.wsgemm(x, wt, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(2, 1, 1, 1, False))
+        op.i[12] = 2                                                                                            # K slices without a workspace
+        validate((op, keep))
+    with pytest.raises(_lib.L2DError):
+        op, keep = ops.wsgemm(x, wt, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(2, 1, 1, 1, False))
+        op.i[20] = 1                                                                                            # LayerNorm fold without column sums
+        validate((op, keep))

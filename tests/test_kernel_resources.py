@@ -70,12 +70,8 @@ def test_occupancy_budgets(kernels):
         assert k["vgpr_count"] + k["agpr_count"] <= 256, (n, k)
     for n, k in pick(r"flash_ring_kernelILi(40|80)ELi1ELi4ELi0E").items():
         assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
-    # KV-cache ring kernel: 5 waves per block, one block per CU (10 waves with the 16-pixel geometry: three on two SIMDs)
-    # round-2 ring form (A/B only; L = 24: one block of 5 waves per CU = at most two waves per SIMD, so up to 256 registers cost nothing)
-    for n, k in pick(r"tattn_stream_ring_kernelILi\d+ELi(12|16)E").items():
-        assert k["vgpr_count"] + k["agpr_count"] <= 168, (n, k)
-    for n, k in pick(r"tattn_stream_ring_kernelILi\d+ELi24E").items():
-        assert k["vgpr_count"] + k["agpr_count"] <= 256, (n, k)
+    # KV-cache attention: the round-2 ring form lives in analysis builds only since round 4
+    assert not [n for n in kernels if "tattn_stream_ring_kernel" in n]
     # loader-wave kernel (the default for every window, scores in LDS): no scratch -- the unrolled form's score array went to
     # scratch at L = 40, and a scratch load would also break the loader's counted vmcnt -- and <= 128 registers
     lw = pick(r"tattn_stream_ringlw_kernel")
