@@ -341,6 +341,76 @@ extern "C" int l2d_ingest_bench(const void *src, void *sink, int64_t region, int
     return l2d_check_launch("ingest_bench", 0);
 }
 
+// Transcendental-issue probe (analysis builds only, tools/exp_probe.py): how many cycles does a wave64 v_exp_f32 cost on gfx950 --
+// alone, with a second wave on the SIMD, and beside dependent MFMAs?  Settles the VALU floor of the flash-attention softmax
+// (one exponential per score).  MODE 0: 16 independent v_exp_f32 per iteration; 1: 16 independent
+// v_add_f32 (the plain-VALU yardstick); 2: 16 v_exp_f32 + 14 v_mfma_f32_16x16x32_f16 on 2 accumulators (the ratio of one 64-key
+// tile of the d = 40 kernel: 32 exponentials to 28 MFMAs per wave); 3: the 14 MFMAs alone; 4: 16 v_add + 14 MFMAs.
+// One block per CU, `waves` per block (4 = one per SIMD, 8 = two per SIMD); out[wave] = cycles for `iters` iterations.
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(512) void exp_probe_kernel(unsigned long long *out, int iters, float seed) {
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = seed * (float)(i + 1 + (threadIdx.x & 7)) * 1e-3f;
+    f32x4p acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    typedef _Float16 hh8 __attribute__((ext_vector_type(8)));
+    hh8 fa, fb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fa[e] = (_Float16)(0.01f * (float)(e + 1)); fb[e] = (_Float16)(0.02f * (float)(e + 1)); }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+                if (MODE == 2 && i < 14) {
+                    if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc0, 0, 0, 0);
+                }
+            }
+        } else if (MODE == 1 || MODE == 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(seed));
+                if (MODE == 4 && i < 14) {
+                    if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc0, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc0, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float sink = acc0[0] + acc1[1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sink += x[i];
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (sink == 1234.5f) ? 0ull : (t1 - t0);
+}
+
+extern "C" int l2d_exp_probe(void *out, int mode, int waves, int iters, void *stream) {
+    if (!out || waves < 1 || waves > 8 || iters <= 0) {
+        l2d_set_error("exp_probe: invalid arguments");
+        return L2D_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((exp_probe_kernel<0>), dim3(256), dim3(64 * waves), 0, s, (unsigned long long *)out, iters, 0.37f); break;
+        case 1: hipLaunchKernelGGL((exp_probe_kernel<1>), dim3(256), dim3(64 * waves), 0, s, (unsigned long long *)out, iters, 0.37f); break;
+        case 2: hipLaunchKernelGGL((exp_probe_kernel<2>), dim3(256), dim3(64 * waves), 0, s, (unsigned long long *)out, iters, 0.37f); break;
+        case 3: hipLaunchKernelGGL((exp_probe_kernel<3>), dim3(256), dim3(64 * waves), 0, s, (unsigned long long *)out, iters, 0.37f); break;
+        default: hipLaunchKernelGGL((exp_probe_kernel<4>), dim3(256), dim3(64 * waves), 0, s, (unsigned long long *)out, iters, 0.37f); break;
+    }
+    return l2d_check_launch("exp_probe", 0);
+}
+
 // Access-pattern probe for the KV-cache stream (analysis builds only, tools/kv_pattern_probe.py).  One 320-thread block per CU
 // streams its private slice of `src` HBM -> LDS with the ring discipline of tattn_ring.hip (NS stages of R DMA wave-instructions,
 // counted vmcnt waits, one barrier per stage) and NO arithmetic.  `pattern` picks what a stage fetches from a group of 8 pixels

@@ -100,8 +100,10 @@ __device__ __forceinline__ void ws_gwait(h16x8 &a, h16x8 &b) { asm volatile("s_w
 // The activation-fragment reads (LDS) are asm for the same reason: behind inline asm hipcc waits lgkmcnt(0) before every use of a
 // double-buffered fragment, i.e. for the reads it has just issued for the NEXT step.  LDS returns in order: with at most N
 // younger reads outstanding the four fragments of this step have landed.
-template <int OFF>
-__device__ __forceinline__ void ws_lread(h16x8 &dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+template <unsigned OFF>
+__device__ __forceinline__ void ws_lread(h16x8 &dst, unsigned addr) {
+    static_assert(OFF < 65536u, "ds_read immediate offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
 template <int N>
 __device__ __forceinline__ void ws_lwait(h16x8 &a, h16x8 &b, h16x8 &c, h16x8 &d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -294,9 +296,15 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 for (int j = 0; j < 8; ++j) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+#ifdef L2D_WS_NODOT
+                        const float x0 = (float)v[j][2 * e], x1 = (float)v[j][2 * e + 1];
+                        sx[j0 + j] += x0; sx[j0 + j] += x1;
+                        sq[j0 + j] = __builtin_fmaf(x0, x0, sq[j0 + j]); sq[j0 + j] = __builtin_fmaf(x1, x1, sq[j0 + j]);
+#else
                         const h16x2 pr = {v[j][2 * e], v[j][2 * e + 1]};
                         sx[j0 + j] = __builtin_amdgcn_fdot2(pr, ones2, sx[j0 + j], false);
                         sq[j0 + j] = __builtin_amdgcn_fdot2(pr, pr, sq[j0 + j], false);
+#endif
                     }
                 }
             }
@@ -321,6 +329,7 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
             if (l == 0 && s < 12) WS_STAMP(4 + 2 * s);
             if (stats) stage_stats(s & (NS - 1));
         }
+        __builtin_amdgcn_s_barrier();          // (the consumers' last stage ends like every other one: with the barrier of a "next" stage)
         if (stats) {
             // the 8 lanes of a token (its 8 channel slots) are adjacent: sum them on DPP, lane qpos == 0 publishes the token's sums
             auto dpp = [](float x, auto ctrl) {
@@ -370,98 +379,122 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
 
         // one stage = 4 k steps on ring slots 4 p .. 4 p + 3.  MORE: another stage follows -- its barrier is met inside this stage's
         // last k step, after the stage's last fragment read, and the next stage's first fragments are fetched under that step's MFMAs
-        auto do_stage = [&](auto pc, auto refill_c, int slot, bool more) {
+        // The LDS slot of a stage is a compile-time constant where the loop structure allows it (RDS == NS: the slot offsets fold into
+        // the ds_read immediates and the k loop holds no VALU instruction at all); with RDS == NS / 2 the slot pair alternates at
+        // run time (SLOT < 0: the slot is `slot_rt`) and costs one v_add per k step.
+        auto do_stage = [&](auto pc, auto refill_c, auto slot_c, int slot_rt) {
             constexpr int p = decltype(pc)::value;
             constexpr bool REFILL = decltype(refill_c)::value;
-            const unsigned sb = slot * (STG * 2), nb = ((slot + 1) & (NS - 1)) * (STG * 2);       // byte offsets of this / the next stage
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                constexpr int j = 4 * p + 0;
-                // LDS queue of this wave, oldest first, when the MFMAs of step u start: this step's 4 fragments | the next step's 4
-                if (u < 3) {
-                    const unsigned ad = xoff[u + 1] + sb;
-                    ws_lread<0>(xf[(u + 1) & 1][0], ad); ws_lread<4096>(xf[(u + 1) & 1][1], ad);
-                    ws_lread<8192>(xf[(u + 1) & 1][2], ad); ws_lread<12288>(xf[(u + 1) & 1][3], ad);
-                    ws_lwait<4>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
-                } else if (more) {
-                    // every fragment of this stage is in registers: meet the loader (it may refill this stage's slot) and fetch the
-                    // next stage's first fragments under this step's MFMAs
-                    ws_lwait<0>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
-                    __builtin_amdgcn_s_barrier();
-                    const unsigned ad = xoff[0] + nb;
-                    ws_lread<0>(xf[0][0], ad); ws_lread<4096>(xf[0][1], ad); ws_lread<8192>(xf[0][2], ad); ws_lread<12288>(xf[0][3], ad);
-                } else {
-                    ws_lwait<0>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);
-                }
+            constexpr int SLOT = decltype(slot_c)::value;
+            constexpr unsigned sb = SLOT < 0 ? 0u : (unsigned)SLOT * (STG * 2);                    // byte offsets of this / the next
+            constexpr unsigned nb = SLOT < 0 ? 0u : (unsigned)((SLOT + 1) & (NS - 1)) * (STG * 2); // stage (static part)
+            const unsigned sbr = SLOT < 0 ? (unsigned)slot_rt * (STG * 2) : 0u;                    // (run-time part)
+            const unsigned nbr = SLOT < 0 ? (unsigned)((slot_rt + 1) & (NS - 1)) * (STG * 2) : 0u;
+            // weights of k step u landed -> its MFMAs -> refill of its ring slot
+            auto compute = [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int j = 4 * p + u;
                 // this k step's weight fragments have landed when only the younger requests are outstanding: NT per later k step
                 // of the ring (main loop: all 4 RDS - 1 of them; the last stages issue no refills and count down)
-                {
-                    const int t = 4 * p + u;                    // (folds: p and u are unrolled constants)
-                    if constexpr (REFILL) {
-                        if constexpr (NT == 1) ws_gwait<4 * RDS - 1>(wr[j + u][0]);
-                        else ws_gwait<2 * (4 * RDS - 1)>(wr[j + u][0], wr[j + u][1]);
-                    } else {
-#define WS_TAIL_WAIT(T) case T: if constexpr (NT == 1) ws_gwait<(4 * RDS - 1 - T > 0 ? 4 * RDS - 1 - T : 0)>(wr[j + u][0]); \
-                                else ws_gwait<(4 * RDS - 1 - T > 0 ? 2 * (4 * RDS - 1 - T) : 0)>(wr[j + u][0], wr[j + u][1]); break;
-                        switch (t) {
-                            WS_TAIL_WAIT(0) WS_TAIL_WAIT(1) WS_TAIL_WAIT(2) WS_TAIL_WAIT(3) WS_TAIL_WAIT(4) WS_TAIL_WAIT(5) WS_TAIL_WAIT(6)
-                            WS_TAIL_WAIT(7) WS_TAIL_WAIT(8) WS_TAIL_WAIT(9) WS_TAIL_WAIT(10) WS_TAIL_WAIT(11) WS_TAIL_WAIT(12)
-                            WS_TAIL_WAIT(13) WS_TAIL_WAIT(14) WS_TAIL_WAIT(15)
-                        }
-#undef WS_TAIL_WAIT
-                    }
+                if constexpr (REFILL) {
+                    ws_gwait<4 * RDS - 1>(wr[j][0]);
+                } else {
+                    ws_gwait<(4 * RDS - 1 - j > 0 ? 4 * RDS - 1 - j : 0)>(wr[j][0]);
                 }
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j + u][i], xf[u & 1][mt], acc[i][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j][0], xf[u & 1][mt], acc[0][mt], 0, 0, 0);
                 if constexpr (REFILL) {
                     const int kn = ks + 4 * RDS;
                     const int kk = kn < ks_last ? kn : ks_last;   // (clamped: the last ring of the slice re-requests its final fragment)
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) ws_gload<NTW>(wr[j + u][i], voff[i], wp + (long long)kk * 512);
+                    ws_gload<NTW>(wr[j][0], voff[0], wp + (long long)kk * 512);
                 }
                 ++ks;
                 __builtin_amdgcn_sched_barrier(0);              // the refills stay HERE: 4 RDS - 1 k steps ahead of their use
+            };
+            auto step = [&](auto uc) {                          // k steps 0..2: request the next step's fragments, wait for this step's
+                constexpr int u = decltype(uc)::value;
+                const unsigned ad = xoff[u + 1] + sbr;           // (+ a static slot, in the immediates: <= 61440)
+                ws_lread<sb>(xf[(u + 1) & 1][0], ad); ws_lread<sb + 4096>(xf[(u + 1) & 1][1], ad);
+                ws_lread<sb + 8192>(xf[(u + 1) & 1][2], ad); ws_lread<sb + 12288>(xf[(u + 1) & 1][3], ad);
+                ws_lwait<4>(xf[u & 1][0], xf[u & 1][1], xf[u & 1][2], xf[u & 1][3]);      // (LDS returns in order: only the 4 reads above are younger)
+                __builtin_amdgcn_sched_barrier(0);              // (the next step's fragment reads stay in FRONT of this step's MFMAs)
+                compute(uc);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            // Last k step.  NOTHING asm-loaded from LDS may be in flight at a basic-block boundary: at control-flow merges the compiler
+            // is free to COPY a fragment register it believes to be valid -- seen in the ISA as v_mov of a fragment whose ds_read had
+            // not been waited for, and on the GPU as wrong rows whenever another kernel on the CU slowed the LDS down.  A stage is
+            // therefore straight-line code that ends with every LDS read it issued waited for; there is no "is there a next stage"
+            // branch: the LAST stage of a slice meets the loader's final barrier and fetches four fragments of a slot nobody will use
+            // (~100 cycles once per block).  (The weight ring crosses the loop back-edge by design; tests/test_kernel_resources.py
+            // replays every path of the ISA for both queues.)
+            ws_lwait<0>(xf[1][0], xf[1][1], xf[1][2], xf[1][3]);
+            __builtin_amdgcn_s_barrier();                       // this wave is done with the stage's slot; the next stage has landed
+            {
+                const unsigned ad = xoff[0] + nbr;
+                ws_lread<nb>(xf[0][0], ad); ws_lread<nb + 4096>(xf[0][1], ad); ws_lread<nb + 8192>(xf[0][2], ad); ws_lread<nb + 12288>(xf[0][3], ad);
             }
+            __builtin_amdgcn_sched_barrier(0);                  // (the next stage's first fragments are fetched under this step's MFMAs)
+            compute(std::integral_constant<int, 3>{});
+            ws_lwait<0>(xf[0][0], xf[0][1], xf[0][2], xf[0][3]);
 #ifdef L2D_PROBES
             { const int sdone = (ks >> 2) - c0 - 1; if (wave == 0 && sdone < 12) WS_STAMP(35 + 2 * sdone); }   // stage done (issue side)
 #endif
         };
-        // main loop: RDS stages per iteration (static ring slots), every one of them followed by another stage
-        int s = 0;
-        for (; s + RDS < n; s += RDS) {
-            do_stage(std::integral_constant<int, 0>{}, std::true_type{}, s & (NS - 1), true);
-            if constexpr (RDS > 1) do_stage(std::integral_constant<int, 1>{}, std::true_type{}, (s + 1) & (NS - 1), true);
-            if constexpr (RDS > 2) do_stage(std::integral_constant<int, 2>{}, std::true_type{}, (s + 2) & (NS - 1), true);
-            if constexpr (RDS > 3) do_stage(std::integral_constant<int, 3>{}, std::true_type{}, (s + 3) & (NS - 1), true);
-        }
-        // the last 1 .. RDS stages: their fragments are already in the ring
-        const int rem = n - s;
-        // (nested, so that the control-flow graph has no path that skips a stage and runs a later one: the ISA check in
-        // tests/test_kernel_resources.py replays every path with the counted waits)
-        do_stage(std::integral_constant<int, 0>{}, std::false_type{}, s & (NS - 1), rem > 1);
-        if constexpr (RDS > 1) {
-            if (rem > 1) {
-                do_stage(std::integral_constant<int, 1>{}, std::false_type{}, (s + 1) & (NS - 1), rem > 2);
-                if constexpr (RDS > 2) {
-                    if (rem > 2) {
-                        do_stage(std::integral_constant<int, 2>{}, std::false_type{}, (s + 2) & (NS - 1), rem > 3);
-                        if constexpr (RDS > 3) {
-                            if (rem > 3) do_stage(std::integral_constant<int, 3>{}, std::false_type{}, (s + 3) & (NS - 1), false);
+        // main loop: RDS stages per iteration (static ring positions)
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+#define WS_C(v) std::integral_constant<int, (v)>{}
+        // the last 1 .. RDS stages: their fragments are already in the ring (no refills).  Nested, so that the control-flow graph has
+        // no path that skips a stage and runs a later one.
+        // BASE >= 0: static slots BASE, BASE + 1, ...; BASE < 0: run-time slots s0, s0 + 1, ...
+        auto tail = [&](auto base_c, int s0, int rem) {
+            constexpr int B0 = decltype(base_c)::value;
+#define WS_SL(k) WS_C(B0 < 0 ? -1 : ((B0 + (k)) & (NS - 1))), ((s0 + (k)) & (NS - 1))
+            do_stage(WS_C(0), F_{}, WS_SL(0));
+            if constexpr (RDS > 1) {
+                if (rem > 1) {
+                    do_stage(WS_C(1), F_{}, WS_SL(1));
+                    if constexpr (RDS > 2) {
+                        if (rem > 2) {
+                            do_stage(WS_C(2), F_{}, WS_SL(2));
+                            if constexpr (RDS > 3) {
+                                if (rem > 3) do_stage(WS_C(3), F_{}, WS_SL(3));
+                            }
                         }
                     }
                 }
             }
+#undef WS_SL
+        };
+        static_assert(RDS == NS || 2 * RDS == NS, "the k loop is written for a register ring of NS or NS / 2 stages");
+        int s = 0;
+        if constexpr (RDS == NS) {
+            for (; s + RDS < n; s += RDS) {
+                do_stage(WS_C(0), T_{}, WS_C(0), 0);
+                do_stage(WS_C(1), T_{}, WS_C(1), 0);
+                do_stage(WS_C(2), T_{}, WS_C(2), 0);
+                do_stage(WS_C(3), T_{}, WS_C(3), 0);
+            }
+            tail(WS_C(0), 0, n - s);
+        } else {
+            for (; s + RDS < n; s += RDS) {
+                do_stage(WS_C(0), T_{}, WS_C(-1), s & (NS - 1));
+                do_stage(WS_C(1), T_{}, WS_C(-1), (s + 1) & (NS - 1));
+            }
+            tail(WS_C(-1), s, n - s);
         }
-        if (wave == 0) WS_STAMP(60);                            // k loop done (issue side)
         // (the clamped duplicates of the last ring: nothing of this wave's is in flight beyond here)
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < 4 * RDS; j += 8)
                 ws_gdrain8(wr[j][i], wr[j + 1][i], wr[j + 2][i], wr[j + 3][i], wr[j + 4][i], wr[j + 5][i], wr[j + 6][i], wr[j + 7][i]);
+#undef WS_C
+        if (wave == 0) WS_STAMP(60);                            // k loop done (issue side)
     }
 
     // ------------------------------------------------------------------------------------------------- epilogue
@@ -752,7 +785,10 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     a.Ktot = a.taps * a.CinP;
     const int tiles = Nout > 0 ? Nout / 32 : 0;
-    const bool geom_ok = (NT == 1 || NT == 2) && NW >= 1 && NW <= (NT == 2 ? 4 : 8) && (NL == 1 || NL == 2) && tiles > 0 &&
+    // (NT = 2, two weight tiles per wave, existed until the middle of round 4: it ran at the 256-register limit -- every change of the
+    //  loop tipped one of its forms into scratch, which the counted vmcnt waits cannot tolerate -- and the in-frame tuner picked it for
+    //  one shape of one configuration)
+    const bool geom_ok = NT == 1 && NW >= 1 && NW <= 8 && (NL == 1 || NL == 2) && tiles > 0 &&
                          (Nout % 32) == 0 && (tiles % (NW * NT)) == 0 && ntr >= 0 && ntr <= tiles && (ntr % (NW * NT)) == 0;
     const bool conv = a.taps == 9;
     if (!a.x1 || !a.w || !a.zero || a.M <= 0 || a.M >= (1 << 22) || (a.taps != 1 && a.taps != 9) || !geom_ok || a.C1 <= 0 || (a.C1 % 64) ||
@@ -809,8 +845,7 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     }
     L2D_DRY_RETURN();
     const int nthr_all = 64 * (NW + NL);
-    if (NT == 2) launch_ws_v<2, 2, 6>(a, NL, ntw, nthr_all, lds, s);
-    else if (NW <= 4) launch_ws_v<1, 4, 6>(a, NL, ntw, nthr_all, lds, s);
+    if (NW <= 4) launch_ws_v<1, 4, 6>(a, NL, ntw, nthr_all, lds, s);
     else launch_ws_v<1, 2, 10>(a, NL, ntw, nthr_all, lds, s);
     return l2d_check_launch("wsgemm", op->tag);
 }

@@ -45,8 +45,8 @@ def _split_bufs(L, M, N, sched):
 
 def _geoms(tiles, ntr_tiles=0, pro=0):
     out = []
-    for nt in (1, 2):
-        for nw in range(1, (4 if nt == 2 else 8) + 1):
+    for nt in (1,):
+        for nw in range(1, 9):
             if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0:
                 out.append((nw, nt))
     return out
@@ -95,7 +95,7 @@ def test_wsgemm_every_geometry(L, K):
                 torch.cuda.synchronize()
                 assert torch.equal(out, out2), f"split-K {sched}: runs differ"
             seen += 1
-    assert seen >= 30
+    assert seen >= 25
 
 
 @pytest.mark.parametrize("M,C,N", [(512, 1280, 3840), (128, 1280, 1280), (2048, 640, 1920), (100, 64, 128), (96, 256, 128)])
@@ -131,7 +131,7 @@ def test_wsgemm_geglu_with_layernorm(L, M, C):
     ref = h[:, :4 * C] * F.gelu(h[:, 4 * C:])
     wp, bp, cs = L.pack_wsgemm(w.to(DEV), b.to(DEV), gm.to(DEV), bt.to(DEV), geglu=True)
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
-    for sched in ((4, 1, 1, 1, False), (4, 2, 1, 1, True), (2, 1, 2, 1, True), (8, 1, 2, 1, False), (1, 2, 1, 1, False), (4, 2, 2, 2, False)):
+    for sched in ((4, 1, 1, 1, False), (5, 1, 1, 1, True), (2, 1, 2, 1, True), (8, 1, 2, 1, False), (1, 1, 1, 1, False), (4, 1, 2, 2, False)):
         if (8 * C // 32) % (sched[0] * sched[1]) or sched[3] > C // 64:
             continue
         L.run(L.wsgemm(x.to(DEV), wp, out, M=M, Nout=8 * C, C1=C, ldx1=C, ldo=4 * C, bias=bp, colsum=cs, pro=1, eps=1e-5, epi=1,
@@ -178,7 +178,7 @@ def test_wsgemm_concat_input(L):
     ref = torch.cat([x1, x2], 1).float() @ w.float().t() + b
     wp, bp, _ = L.pack_wsgemm(w.to(DEV), b.to(DEV))
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
-    for sched in ((4, 1, 1, 1, False), (2, 2, 1, 3, False)):
+    for sched in ((4, 1, 1, 1, False), (2, 1, 2, 3, False)):
         L.run(L.wsgemm(x1.to(DEV), wp, out, M=M, Nout=N, C1=C1, ldx1=C1, x2=x2.to(DEV), C2=C2, ldx2=C2, ldo=N, bias=bp, sched=sched,
                        **_split_bufs(L, M, N, sched)))
         torch.cuda.synchronize()
@@ -237,7 +237,7 @@ def test_wsgemm_groupnorm_statistics_of_the_output(L, B, T, K, C, choff2, Ccat, 
     out = torch.empty(M, C, dtype=torch.float16, device=DEV)
     acc = torch.zeros(2, B, G, 2, dtype=torch.int64, device=DEV)
     cpg1, cpg2 = C // G, Ccat // G
-    for sched in ((4, 1, 1, 1, False), (2, 1, 1, 1, False), (2, 1, 2, 4, False)) + (((4, 2, 1, 2, False),) if C % 256 == 0 else ()):
+    for sched in ((4, 1, 1, 1, False), (2, 1, 1, 1, False), (2, 1, 2, 4, False)) + (((8, 1, 1, 2, False),) if C % 256 == 0 else ()):
         if (C // 32) % (sched[0] * sched[1]) or sched[3] > taps * K // 64:
             continue
         accs = []

@@ -173,7 +173,7 @@ def main():
         nch = Ktot // 64
         tiles = N // 32
         rows = []
-        for nw, nt in ((1, 1), (2, 1), (4, 1), (8, 1), (5, 1), (2, 2), (4, 2)):
+        for nw, nt in ((1, 1), (2, 1), (4, 1), (8, 1), (5, 1)):
             if tiles % (nw * nt):
                 continue
             ny = tiles // (nw * nt)

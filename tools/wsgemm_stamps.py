@@ -18,8 +18,7 @@ CASES = [  # (name, kind, M, K (or C), N, pro, epi, sched)
     ("GEGLU M128", "lin", 128, 1280, 10240, 1, 1, (4, 1, 2, 1, True)),
     ("GEGLU M128 S2", "lin", 128, 1280, 10240, 1, 1, (4, 1, 2, 2, True)),
     ("GEGLU M512", "lin", 512, 1280, 10240, 1, 1, (4, 1, 2, 1, False)),
-    ("GEGLU M512 NT2", "lin", 512, 1280, 10240, 1, 1, (4, 2, 2, 1, False)),
-    ("FF2 M512 NT2", "lin", 512, 5120, 1280, 0, 0, (2, 2, 2, 3, False)),
+    ("GEGLU M512 w5", "lin", 512, 1280, 10240, 1, 1, (5, 1, 2, 1, False)),
     ("FF2 M512", "lin", 512, 5120, 1280, 0, 0, (2, 1, 2, 3, False)),
     ("conv M128", "conv", 128, 1280, 1280, 0, 0, (2, 1, 2, 12, True)),
     ("conv M128 BN128", "conv", 128, 1280, 1280, 0, 0, (4, 1, 2, 12, True)),
