@@ -296,15 +296,9 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 for (int j = 0; j < 8; ++j) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-#ifdef L2D_WS_NODOT
-                        const float x0 = (float)v[j][2 * e], x1 = (float)v[j][2 * e + 1];
-                        sx[j0 + j] += x0; sx[j0 + j] += x1;
-                        sq[j0 + j] = __builtin_fmaf(x0, x0, sq[j0 + j]); sq[j0 + j] = __builtin_fmaf(x1, x1, sq[j0 + j]);
-#else
                         const h16x2 pr = {v[j][2 * e], v[j][2 * e + 1]};
                         sx[j0 + j] = __builtin_amdgcn_fdot2(pr, ones2, sx[j0 + j], false);
                         sq[j0 + j] = __builtin_amdgcn_fdot2(pr, pr, sq[j0 + j], false);
-#endif
                     }
                 }
             }
