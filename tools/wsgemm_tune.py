@@ -91,7 +91,7 @@ def main():
     lines = [f"default schedules: frame (sum of in-frame launch times) {frame0 / 1e3:.3f} ms"]
     for nw, nt in ((1, 1), (2, 1), (4, 1), (5, 1), (8, 1)):
         for S in (1, 2, 3, 4, 6, 8, 12):
-            for nl in (2, 1):
+            for nl in (2,):                  # (one loader wave never won a shape in rounds of tuning; the kernel keeps the form)
                 res, _c, fr = measure((nw, nt, nl, S))
                 for (key, sched), t in res.items():
                     if sched != (nw, nt, nl, S):
@@ -121,8 +121,9 @@ def main():
     if os.path.exists(args.out):
         d_ = json.load(open(args.out))
         prev, prev_skip = d_.get("shapes", {}), d_.get("skip", [])
-    prev.update(table)
     measured = set(best)
+    prev = {k: v for k, v in prev.items() if k not in measured}       # (a shape measured now loses its older pick)
+    prev.update(table)
     prev_skip = sorted((set(prev_skip) - measured) | set(skip))
     with open(args.out, "w") as f:
         json.dump({"note": "in-frame picks of tools/wsgemm_tune.py: key = taps,M,Ktot,Nout,ntr,epi,pro -> [NW, NT, NL, S]; skip = shapes "
