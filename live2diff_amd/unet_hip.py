@@ -405,7 +405,10 @@ class HipStreamingUNet:
             if int(meta["window"]) != self.cfg.window_size or json.loads(meta["block_out_channels"]) != list(self.cfg.block_out_channels):
                 raise ValueError(f"{path}: packed for window {meta['window']} / widths {meta['block_out_channels']}, "
                                  f"this instance is window {self.cfg.window_size} / {list(self.cfg.block_out_channels)}")
-            self.W = {k: f.get_tensor(k).to(self.device) for k in f.keys()}
+            # (a copy in every case: on the CPU -- dry-run plans of the test-suite -- get_tensor() returns a view into the file buffer
+            #  whose address need not be 16-byte aligned, which the launch validation requires of every pointer)
+            self.W = {k: (f.get_tensor(k).to(self.device) if torch.device(self.device).type != "cpu" else f.get_tensor(k).clone())
+                      for k in f.keys()}
         self.temb_offsets = {k: int(v) for k, v in json.loads(meta["temb_offsets"]).items()}
         self.text_offsets = {k: int(v) for k, v in json.loads(meta["text_offsets"]).items()}
         self.n_map_blocks = int(meta["n_map_blocks"])
