@@ -478,12 +478,6 @@ static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
     if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
         const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
         geo = (big >= 384) ? 2 : 3;
-        static int forced = -1;            // tuning knob: L2D_FLASH_GEO overrides the auto choice where the geometry exists
-        if (forced < 0) {
-            const char *e = getenv("L2D_FLASH_GEO");
-            forced = e ? atoi(e) : 0;
-        }
-        if (forced >= 2 && forced <= 3 && big >= 384) geo = forced;
     }
     if constexpr (D <= 80) {          // d = 160 with 32 query rows per wave does not fit the register file
         if (geo == 2) return launch_far_q<D, 2, 4, 0>(a, s);
@@ -499,12 +493,7 @@ int l2d_launch_flash_ring(const l2d_op *op, int geo, hipStream_t s) {
 #ifdef L2D_PROBES
     a.probe = g_flash_probe;
 #endif
-    static int xcd_order = -1;          // A/B knob: L2D_FLASH_XCD=0 keeps the plain (q-block fastest) block order
-    if (xcd_order < 0) {
-        const char *e = getenv("L2D_FLASH_XCD");
-        xcd_order = (e && e[0] == '0') ? 0 : 1;
-    }
-    a.xcd = xcd_order;
+    a.xcd = 1;                          // XCD-contiguous block order (the plain order measured the same: round 2)
     a.B = op->i[0]; a.H = op->i[1]; a.d = op->i[2]; a.Tq = op->i[3]; a.Tk = op->i[4];
     a.ldq = op->i[5]; a.ldk = op->i[6]; a.ldvt = op->i[7]; a.ldo = op->i[8];
     a.sq = op->l[0]; a.sk = op->l[1]; a.svt = op->l[2]; a.so = op->l[3];

@@ -209,15 +209,12 @@ def pconv_patch(B: int, H: int, W: int, Nout: int, C1: int, C2: int = 0):
     resolutions: with few tokens the launch is bound by its weight stream (9 C Nout x 2 bytes), which wants split-K."""
     if os.environ.get("L2D_PCONV", "1") == "0" or Nout % 64 or C1 % 64 or C2 % 64 or C1 <= 0:
         return None
-    force = os.environ.get("L2D_PCONV_PATCH")
     for ph, pw in ((8, 16), (8, 8), (4, 8)):
         if H % ph or W % pw:
             continue
-        if force and force != f"{ph}x{pw}":
-            continue
         blocks = B * (H // ph) * (W // pw) * (Nout // 64)
         tokens = B * H * W
-        if blocks >= 256 and tokens >= int(os.environ.get("L2D_PCONV_MIN_TOKENS", "2048")):
+        if blocks >= 256 and tokens >= 2048:
             return ph, pw
     return None
 
@@ -580,8 +577,7 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, tap
             return t, S, v
     elif key in _TUNED:
         return tuple(_TUNED[key])
-    v_small = int(os.environ.get("L2D_IGEMM_V_SMALL", "1"))     # BK64 x 3 stages: in-frame best (85.3 vs 79.9 fps with x2)
-    v_big = int(os.environ.get("L2D_IGEMM_V_BIG", "5"))
+    v_small, v_big = 1, 5           # BK64 x 3 stages: in-frame best (85.3 vs 79.9 fps with x2); 128x128 BK32 x 4 for the big shapes
     cdiv = lambda a, b: (a + b - 1) // b
     nk64 = Kp // 64
     big = cdiv(Nout, 128) * cdiv(M, 128) * batch
@@ -647,7 +643,7 @@ def igemm(x1, w, out, *, M, Nout, C1, ldx1, CinP, ldo, x2=None, C2=0, ldx2=0, bi
         op.p[11] = _ptr(cnt) + 4 * cnt_off
     elif splitk > 1:
         assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= batch * splitk * M * round_up(Nout, 4)
-    direct_epi = 32 if os.environ.get("L2D_IGEMM_EPI", "1") == "0" else 0     # A/B knob: register -> global epilogue
+    direct_epi = 0                  # (bit 5 of i22 selects the round-1 register -> global epilogue: A/B settled in round 2)
     vals = [taps, C1, C2, ldx1, ldx2, CinP, B, Hin, Win, Hout, Wout, stride, ups, M, Nout, ldo, ldr, ldrb,
             rows_per_bias, epi, batch, splitk, int(tile) + 16 * int(order) + direct_epi, variant]
     for j, v in enumerate(vals):
@@ -664,8 +660,8 @@ def splitk_sizes(M: int, Nout: int, splitk: int, batch: int, tile: int):
     return batch * ntiles * splitk * t * t, batch * ntiles
 
 
-SPLITK_FUSED = os.environ.get("L2D_IGEMM_SPLITK_FUSED", "1") != "0"     # A/B knob: 0 = separate reduction launch (round 1)
-SPLITK_FUSED_MAX = int(os.environ.get("L2D_IGEMM_SPLITK_FUSED_MAX", "16"))     # deeper splits keep the reduction launch: ONE block
+SPLITK_FUSED = True              # (False = separate reduction launch, the round-1 form: A/B settled in round 3)
+SPLITK_FUSED_MAX = 16            # deeper splits keep the reduction launch: ONE block
 # per tile sums all S slabs in the fused form, which serialises when a launch has few tiles and many splits (8x8 levels)
 
 

@@ -111,7 +111,7 @@ class HipStreamingUNet:
         #                                    fresh tensor); False (default): a view of the static output buffer, like a TensorRT binding
         self.tattn_variant = tattn_variant
         self.igemm_splitk_off = False       # tuning knob: disable split-K schedules
-        self.cond_cache = os.environ.get("L2D_COND_CACHE", "1") != "0"   # 0: re-run the conditioning launches every call
+        self.cond_cache = True           # False: re-run the conditioning launches every call (tests)
         assert 1 <= text_len <= TEXT_PAD
         self.text_len = text_len           # static number of text tokens (77 for CLIP)
         self.dtype = torch.float16
@@ -483,7 +483,7 @@ class HipStreamingUNet:
             # XCD tile order: weight-tile major when the weight matrix outweighs the activations (L2 fills, see igemm.hip)
             wbytes = kw["Nout"] * taps * kw["CinP"]
             xbytes = kw["M"] * (kw["C1"] + kw.get("C2", 0))
-            order = {"0": 0, "1": 1}.get(os.environ.get("L2D_IGEMM_ORDER", ""), int(wbytes > xbytes))
+            order = int(wbytes > xbytes)
             op = add(ops.igemm(x1, wt, out, splitk=S, tile=tile, ws=ws, variant=variant, order=order, **cnt_kw, **kw))
             ar.release(ws)
             return op
@@ -549,7 +549,7 @@ class HipStreamingUNet:
                                  ld1=x.C, G=G, nchunk=0, x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2,
                                  acc_ptr=acc_ptr))
                 return out
-            nchunk = max(1, min(int(os.environ.get("L2D_GN_NCHUNK", "64")), T // 16))
+            nchunk = max(1, min(64, T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
                       ld2=C2)
@@ -882,7 +882,7 @@ class HipStreamingUNet:
 
         cur[0] = pl
         # ---- GroupNorm statistics accumulators (one [B][G][2] int64 block per fused GroupNorm), zeroed once per frame
-        st.gn_fuse = os.environ.get("L2D_GN_FUSE", "1") != "0" and os.environ.get("L2D_IGEMM_EPI", "1") != "0"
+        st.gn_fuse = os.environ.get("L2D_GN_FUSE", "1") != "0"
         st.gn_layers, st.gn_stats_launches = 0, 0
         st.gn_acc = torch.zeros(96, B, G, 2, dtype=torch.int64, device=dev)
         st.gn_zero = torch.zeros_like(st.gn_acc)
