@@ -666,6 +666,17 @@ def main():
                                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                                                   "traffic": ((json.load(open(tpath)).get("tattn_stream_kernel") or {}).get("hbm_bytes_per_launch")
                                                               if os.path.exists(tpath) else None)}
+        # the flash kernel: priced against the MFMA peak; the floor evidence is the round-4 probe
+        fl_ = rows.get("flash_attn_kernel")
+        if fl_ and fl_["flops"] > 0:
+            ach = fl_["flops"] / (fl_["ms"] * 1e-3) / 1e12
+            result["roofline_flash"] = {"kernel": "flash_ring_kernel", "bound": "mfma", "launches": fl_["launches"],
+                                        "ms_per_frame": round(fl_["ms"], 4), "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                                        "floor_evidence": "profiles/round4_n_exp_probe.txt: v_exp_f32 = 1.66 plain VALU issues per wave64 with two "
+                                                          "waves per SIMD (2.62 alone); d = 40 loop body: 28 MFMA 16x16x32 (448 cycles) vs 59 VALU + 32 "
+                                                          "exp (~448 cycles) per wave and 64-key tile, measured tile period 2344 cycles: bound by one "
+                                                          "wave's softmax dependency chain at two waves per SIMD, not by either pipe"}
         # measured copy bandwidth for context
         try:
             import ctypes
