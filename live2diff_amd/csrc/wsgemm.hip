@@ -10,21 +10,22 @@
 // kernels served them at 0.5-0.9 TB/s: igemm.hip stages BOTH operands through LDS with 64 / 128-token tiles
 // (every block re-ingests its activation tile per channel tile, ~14-22 B/clk/CU by LDS-DMA), rowgemm.hip keeps 32 tokens resident
 // and therefore reads every weight byte M / 32 times.  Here:
-//   * a block owns 128 tokens (ALL of them at the 8x8 level) x BN = 32 NW NT output channels x one K slice (grid = row tiles x
+//   * a block owns 128 tokens (ALL of them at the 8x8 level) x BN = 32 NW output channels x one K slice (grid = row tiles x
 //     channel tiles x S slices): every weight byte is fetched by exactly one wave per row tile -- once from HBM at M = 128;
-//   * weights never touch LDS: fragment-packed at load time ([n tile 32][k step 16][lane][8 halfs], ops.pack_rowgemm), each
-//     consumer wave streams its own tiles HBM / L2 -> VGPR through a register ring of 8-16 fragments (1 KB, perfectly coalesced,
-//     optionally non-temporal when no second row tile will read them) and feeds each fragment to FOUR v_mfma_f32_32x32x16_f16
-//     (one per 32-token tile);
+//   * weights never touch LDS: fragment-packed at load time ([n tile 32][k step 16][lane][8 halfs], ops.pack_wsgemm /
+//     pack_wsgemm_conv3x3), each consumer wave streams its ONE 32-row tile HBM / L2 -> VGPR through a register ring of 8-16
+//     fragments (1 KB, perfectly coalesced, optionally non-temporal when no second row tile will read them; inline-asm loads
+//     with hand-counted vmcnt waits, see ws_gload) and feeds each fragment to FOUR v_mfma_f32_32x32x16_f16 (one per 32-token
+//     tile);
 //   * the 128-token activation operand is K-chunked: 64 channels (16 KB) per stage through a 4-stage LDS ring filled by dedicated
 //     LOADER wave(s) with global_load_lds (16 B per lane, no VGPR staging; the XOR bank swizzle is applied to the SOURCE slot
 //     because the DMA image is lane-linear), one s_barrier per stage; a 3x3 conv is the same loop with (tap, channel chunk)
 //     stages whose source row is the token's neighbour pixel or the zero page (padding), incl. the two-pointer channel concat;
 //   * LayerNorm in front of the layer costs nothing in the loop: gamma / beta are folded into the packed weights (W diag(gamma),
 //     b + W beta) and the normalisation itself is applied to the ACCUMULATOR, out = rstd (acc - mean colsum(W')) + b', with the
-//     row statistics summed by the consumers from the fragments they multiply anyway (v_dot2 on one of the four token tiles per
-//     wave) -- the activations enter the matrix cores raw (fp16 as stored), which is closer to exact than the reference's
-//     fp16-rounded norm output;
+//     row statistics summed by the LOADER waves from the bytes they moved (v_dot2 on a read-back of their own DMA'd 16 bytes per
+//     lane) -- the consumers' loop is identical with and without the norm, and the activations enter the matrix cores raw (fp16
+//     as stored), which is closer to exact than the reference's fp16-rounded norm output;
 //   * split-K with the reduction fused as in igemm.hip: fp32 partial tiles (and partial row statistics) leave as write-through
 //     (sc1) buffer stores into a tile-private slab, an arrival counter picks the last block, which sums the S slabs in the fixed
 //     order 0..S-1 (bit-repeatable) and runs the epilogue; no fences (igemm.hip explains why);
@@ -32,6 +33,7 @@
 //     per lane, residual added in fp16 on the way, GroupNorm statistics of the output as fixed-point integer atomics (per
 //     sample: a 128-token tile may span samples at the 8x8 level), V^T staging for the flash kernel.
 // Rounding points: GEMM output (+ bias, activation in fp32) -> fp16, residual add in fp16 (as igemm / rowgemm).
+// This file is compiled WITHOUT packed fp32 VALU instructions (csrc/Makefile; DESIGN.md 7.0 has the measurement that led to it).
 #include <type_traits>
 
 #include "common.h"
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
     const int l32 = lane & 31, lh = lane >> 5;
 
     // row phase geometry of the epilogue (whole output rows, 16 bytes per lane): thread -> (row rr + k RPP, 8-channel chunk cc),
-    // k < 8 NT.  The residual rows are requested EARLY: with one weight tile per wave (NT = 1: registers to spare) in front of the
-    // weight ring -- they are older than every fragment in the in-order VMEM queue, so the first counted wait of the k loop covers
-    // them and they cost no round trip of their own -- with two tiles right behind the k loop, under the tile staging.
+    // k < 8.  The residual rows are requested EARLY where registers allow (the <= 6-wave forms): in front of the weight ring --
+    // they are older than every fragment in the in-order VMEM queue, so the first counted wait of the k loop covers them and they
+    // cost no round trip of their own; the 10-wave forms (168-register budget) request them right behind the k loop.
     const int BNp = NW * NT * 32;                              // packed weight rows of this block
     const int BNo = a.epi == 1 ? BNp >> 1 : BNp;               // output columns
     const int nb_p = y * BNp, nb_o = y * BNo;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
         if (wave == 0) WS_STAMP(34);
         ws_lread<0>(xf[0][0], xoff[0]); ws_lread<4096>(xf[0][1], xoff[0]); ws_lread<8192>(xf[0][2], xoff[0]); ws_lread<12288>(xf[0][3], xoff[0]);
 
-        // one stage = 4 k steps on ring slots 4 p .. 4 p + 3.  MORE: another stage follows -- its barrier is met inside this stage's
+        // one stage = 4 k steps on ring positions 4 p .. 4 p + 3; the NEXT stage's barrier is met inside this stage's
         // last k step, after the stage's last fragment read, and the next stage's first fragments are fetched under that step's MFMAs
         // The LDS slot of a stage is a compile-time constant where the loop structure allows it (RDS == NS: the slot offsets fold into
         // the ds_read immediates and the k loop holds no VALU instruction at all); with RDS == NS / 2 the slot pair alternates at
