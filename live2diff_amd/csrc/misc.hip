@@ -411,6 +411,105 @@ extern "C" int l2d_exp_probe(void *out, int mode, int waves, int iters, void *st
     return l2d_check_launch("exp_probe", 0);
 }
 
+// Reproducer attempt for the round-4 packed-fp32 finding (tools/pk_repro.py): the LayerNorm-fold arithmetic of
+// wsgemm.hip's epilogue in isolation -- per lane out[e] = bias[e] + (acc[e] * rstd + colsum[e] * nmr), once on 2-vectors (hipcc emits
+// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, as in the kernel before the fix) and once element by element behind opaque barriers
+// (scalar v_mul / v_fma / v_add, the same rounding steps) -- compared bit for bit in the kernel.  Geometry as the kernel's: four
+// working waves with the parameters in LDS (bias | colsum as ds_read_b128, rstd | nmr per token as ds_read2_b32), a staged fp16
+// tile (ds_write_b64), and two more waves that sleep at the final barrier on the SIMDs of waves 0 and 1.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4p __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(384) void pk_repro_kernel(const float *par_g, const float *stat_g, unsigned int *nbad, unsigned int *first, int iters) {
+    __shared__ __attribute__((aligned(16))) float par[512];
+    __shared__ __attribute__((aligned(16))) float stat[256];
+    __shared__ __attribute__((aligned(16))) _Float16 os[128 * 136];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+    for (int i = tid; i < 512; i += blockDim.x) par[i] = par_g[i];
+    for (int i = tid; i < 256; i += blockDim.x) stat[i] = stat_g[i];
+    __syncthreads();
+    if (wave >= 4) { __syncthreads(); return; }
+    float acc[4][16];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = (float)((lane * 37 + mt * 11 + r * 5 + (int)blockIdx.x) % 97) * 0.03125f - 1.5f;
+    unsigned int bad = 0, where = 0xffffffffu;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int ch = wave * 32 + 8 * g4 + 4 * lh;
+            const f32x4p bb = *reinterpret_cast<const f32x4p *>(par + ch), cs = *reinterpret_cast<const f32x4p *>(par + 256 + ch);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                float rsd = stat[(32 * mt + l32) * 2], nmr = stat[(32 * mt + l32) * 2 + 1];
+                // MODE 1: idle cycles between the LDS wait and the first packed instruction that reads the loaded registers;
+                // MODE 2: one plain VALU copy of the loaded values in between (the packed instructions read the copies)
+                if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(rsd), "+v"(nmr));
+                if constexpr (MODE == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(rsd), "+v"(nmr));
+                h16x4p o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2p c = {cs[2 * h], cs[2 * h + 1]}, a = {acc[mt][4 * g4 + 2 * h], acc[mt][4 * g4 + 2 * h + 1]};
+                    const f32x2p b = {bb[2 * h], bb[2 * h + 1]};
+                    f32x2p p = c * nmr;
+                    asm volatile("" : "+v"(p));
+                    p = a * rsd + p;
+                    asm volatile("" : "+v"(p));
+                    const f32x2p v = b + p;
+                    const float vv[2] = {v.x, v.y};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float r = cs[2 * h + e] * nmr;
+                        asm volatile("" : "+v"(r));
+                        r = __builtin_fmaf(acc[mt][4 * g4 + 2 * h + e], rsd, r);
+                        asm volatile("" : "+v"(r));
+                        r = bb[2 * h + e] + r;
+                        asm volatile("" : "+v"(r));
+                        if (__builtin_bit_cast(unsigned int, r) != __builtin_bit_cast(unsigned int, vv[e])) {
+                            ++bad;
+                            if (where == 0xffffffffu) where = (unsigned int)((lane << 16) | (mt << 12) | (g4 << 8) | ((2 * h + e) << 4) | (wave));
+                        }
+                        o[2 * h + e] = (_Float16)vv[e];
+                    }
+                }
+                *reinterpret_cast<h16x4p *>(os + (32 * mt + l32) * 136 + wave * 32 + 8 * g4 + 4 * lh) = o;
+            }
+        }
+        // perturb the accumulators so that iterations differ (exactly representable steps)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = acc[mt][r] * -1.0f + 0.0078125f * (float)((it + r) & 3);
+    }
+    if (bad) {
+        atomicAdd(nbad, bad);
+        const unsigned int slot = atomicAdd(nbad + 1, 1u);
+        if (slot < 16) { first[2 * slot] = where; first[2 * slot + 1] = blockIdx.x; }
+    }
+    if (os[tid] == (_Float16)12345.0f) nbad[2] = 1;          // (keeps the staged tile alive)
+    __syncthreads();
+}
+
+extern "C" int l2d_pk_repro(const void *par, const void *stat, void *nbad, void *first, int blocks, int iters, void *stream) {
+    if (!par || !stat || !nbad || !first || blocks <= 0 || iters <= 0) {
+        l2d_set_error("pk_repro: invalid arguments");
+        return L2D_EINVAL;
+    }
+    const int mode = blocks >> 16;
+    blocks &= 0xffff;
+    if (mode == 1)
+        hipLaunchKernelGGL(pk_repro_kernel<1>, dim3(blocks), dim3(384), 0, (hipStream_t)stream, (const float *)par, (const float *)stat,
+                           (unsigned int *)nbad, (unsigned int *)first, iters);
+    else if (mode == 2)
+        hipLaunchKernelGGL(pk_repro_kernel<2>, dim3(blocks), dim3(384), 0, (hipStream_t)stream, (const float *)par, (const float *)stat,
+                           (unsigned int *)nbad, (unsigned int *)first, iters);
+    else
+        hipLaunchKernelGGL(pk_repro_kernel<0>, dim3(blocks), dim3(384), 0, (hipStream_t)stream, (const float *)par, (const float *)stat,
+                           (unsigned int *)nbad, (unsigned int *)first, iters);
+    return l2d_check_launch("pk_repro", 0);
+}
+
 // Access-pattern probe for the KV-cache stream (analysis builds only, tools/kv_pattern_probe.py).  One 320-thread block per CU
 // streams its private slice of `src` HBM -> LDS with the ring discipline of tattn_ring.hip (NS stages of R DMA wave-instructions,
 // counted vmcnt waits, one barrier per stage) and NO arithmetic.  `pattern` picks what a stage fetches from a group of 8 pixels

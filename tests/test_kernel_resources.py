@@ -236,20 +236,19 @@ def test_wsgemm_lds_fragment_registers_are_untouched_in_flight(kernels):
     assert n_checked == 8, n_checked
 
 
-def test_wsgemm_has_no_packed_fp32_math(kernels):
-    """wsgemm.hip is compiled with the packed-fp32 feature off (csrc/Makefile): with v_pk_mul_f32 / v_pk_fma_f32 in its LayerNorm-fold
-    epilogue the kernel's output depended -- rarely, and only while another kernel shared the GPU -- on the machine's load (the
-    colsum product of ONE instruction came out 0 in its last 16 lanes; round 4, tools/wsgemm_diag.py and tools/frame_stress.py).
-    The flag is one line in a Makefile; this keeps it from getting lost."""
+def test_no_kernel_uses_packed_fp32_math(kernels):
+    """The library is compiled with the packed-fp32 feature off (csrc/Makefile): with v_pk_mul_f32 / v_pk_fma_f32 in wsgemm's
+    LayerNorm-fold epilogue the kernel's output depended -- only while another kernel shared the GPU -- on the machine's load (the
+    colsum product of ONE instruction came out 0 in its last 16 lanes; round 4, tools/wsgemm_diag.py, tools/frame_stress.py), and the
+    arithmetic reproduces in isolation (tools/pk_repro.py).  The flag is one line in a Makefile; this keeps it from getting lost."""
     objdump = os.path.join(LLVM, "llvm-objdump")
-    seen = 0
+    seen_ws = 0
     for co in kernels["__code_objects__"]:
         dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
         for fn in re.split(r"\n(?=[0-9a-f]+ <)", dis):
             head = fn.split("\n", 1)[0]
-            if "wsgemm_kernel" not in head:
-                continue
-            seen += 1
+            if "wsgemm_kernel" in head:
+                seen_ws += 1
             bad = sorted(set(re.findall(r"\bv_pk_\w+_f32\b", fn)))
             assert not bad, (head, bad)
-    assert seen == 8, seen
+    assert seen_ws == 8, seen_ws
