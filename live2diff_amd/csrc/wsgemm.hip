@@ -392,18 +392,23 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 constexpr int j = 4 * p + u;
                 // this k step's weight fragments have landed when only the younger requests are outstanding: NT per later k step
                 // of the ring (main loop: all 4 RDS - 1 of them; the last stages issue no refills and count down)
-                if constexpr (REFILL) {
-                    ws_gwait<4 * RDS - 1>(wr[j][0]);
+                if constexpr (NT == 1) {
+                    if constexpr (REFILL) ws_gwait<4 * RDS - 1>(wr[j][0]);
+                    else ws_gwait<(4 * RDS - 1 - j > 0 ? 4 * RDS - 1 - j : 0)>(wr[j][0]);
                 } else {
-                    ws_gwait<(4 * RDS - 1 - j > 0 ? 4 * RDS - 1 - j : 0)>(wr[j][0]);
+                    if constexpr (REFILL) ws_gwait<2 * (4 * RDS - 1)>(wr[j][0], wr[j][1]);
+                    else ws_gwait<(4 * RDS - 1 - j > 0 ? 2 * (4 * RDS - 1 - j) : 0)>(wr[j][0], wr[j][1]);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[0][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j][0], xf[u & 1][mt], acc[0][mt], 0, 0, 0);
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[j][i], xf[u & 1][mt], acc[i][mt], 0, 0, 0);
                 if constexpr (REFILL) {
                     const int kn = ks + 4 * RDS;
                     const int kk = kn < ks_last ? kn : ks_last;   // (clamped: the last ring of the slice re-requests its final fragment)
-                    ws_gload<NTW>(wr[j][0], voff[0], wp + (long long)kk * 512);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) ws_gload<NTW>(wr[j][i], voff[i], wp + (long long)kk * 512);
                 }
                 ++ks;
                 __builtin_amdgcn_sched_barrier(0);              // the refills stay HERE: 4 RDS - 1 k steps ahead of their use
@@ -781,10 +786,10 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     a.Ktot = a.taps * a.CinP;
     const int tiles = Nout > 0 ? Nout / 32 : 0;
-    // (NT = 2, two weight tiles per wave, existed until the middle of round 4: it ran at the 256-register limit -- every change of the
-    //  loop tipped one of its forms into scratch, which the counted vmcnt waits cannot tolerate -- and the in-frame tuner picked it for
-    //  one shape of one configuration)
-    const bool geom_ok = NT == 1 && NW >= 1 && NW <= 8 && (NL == 1 || NL == 2) && tiles > 0 &&
+    // NT = 2 (two weight tiles per consumer wave: half the activation re-reads from L2) runs with a register ring of 2 stages instead
+    // of 4 and at most 4 consumer waves: 234 VGPRs, no scratch (its first form, ring of 4, ran AT the 256-register limit and was
+    // removed in the middle of round 4; tests/test_kernel_resources.py replays this one like the others).
+    const bool geom_ok = (NT == 1 || (NT == 2 && NW <= 4)) && NW >= 1 && NW <= 8 && (NL == 1 || NL == 2) && tiles > 0 &&
                          (Nout % 32) == 0 && (tiles % (NW * NT)) == 0 && ntr >= 0 && ntr <= tiles && (ntr % (NW * NT)) == 0;
     const bool conv = a.taps == 9;
     if (!a.x1 || !a.w || !a.zero || a.M <= 0 || a.M >= (1 << 22) || (a.taps != 1 && a.taps != 9) || !geom_ok || a.C1 <= 0 || (a.C1 % 64) ||
@@ -841,7 +846,8 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     }
     L2D_DRY_RETURN();
     const int nthr_all = 64 * (NW + NL);
-    if (NW <= 4) launch_ws_v<1, 4, 6>(a, NL, ntw, nthr_all, lds, s);
+    if (NT == 2) launch_ws_v<2, 2, 6>(a, NL, ntw, nthr_all, lds, s);
+    else if (NW <= 4) launch_ws_v<1, 4, 6>(a, NL, ntw, nthr_all, lds, s);
     else launch_ws_v<1, 2, 10>(a, NL, ntw, nthr_all, lds, s);
     return l2d_check_launch("wsgemm", op->tag);
 }

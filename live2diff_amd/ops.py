@@ -423,8 +423,8 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
     ntw = nm == 1
     key = wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro)
     cands = []
-    for nt in (1,):                                    # (one 32-row weight tile per consumer wave)
-        for nw in range(1, 9):
+    for nt in (1, 2):                                  # 32-row weight tiles per consumer wave (2: at most 4 consumer waves)
+        for nw in range(1, 9 if nt == 1 else 5):
             if tiles % (nw * nt) or (ntr // 32) % (nw * nt):
                 continue
             if _ws_lds(nw, nt, epi, ntr, True) > 163840:

@@ -89,7 +89,7 @@ def main():
     best = {k[0]: (t, k[1]) for k, t in base.items()}
     default = dict(best)
     lines = [f"default schedules: frame (sum of in-frame launch times) {frame0 / 1e3:.3f} ms"]
-    for nw, nt in ((1, 1), (2, 1), (4, 1), (5, 1), (8, 1)):
+    for nw, nt in ((1, 1), (2, 1), (4, 1), (5, 1), (8, 1), (2, 2), (4, 2)):
         for S in (1, 2, 3, 4, 6, 8, 12):
             for nl in (2,):                  # (one loader wave never won a shape in rounds of tuning; the kernel keeps the form)
                 res, _c, fr = measure((nw, nt, nl, S))
