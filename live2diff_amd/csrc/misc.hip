@@ -53,8 +53,13 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(const h16 *__restric
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             h16x8 x = l2d_ld8(A + (long long)m * lda + vc * 8);
+            // v_dot2_f32_f16 for EVERY row, spelled out: left to the compiler (`acc += (float) w[e] * (float) x[e]`, fp-contract
+            // fast) the unrolled rows of one thread got DIFFERENT instruction sequences -- row 0 a chain of v_fma_mix_f32, row 1
+            // v_dot2c_f32_f16 (round 5: seen in the ISA once packed fp32 math was switched off) -- and with them different
+            // roundings: the stream-batch rows of the time embedding stopped being interchangeable
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[m] += (float)w[e] * (float)x[e];
+            for (int e = 0; e < 4; ++e)
+                acc[m] = __builtin_amdgcn_fdot2((h16x2){w[2 * e], w[2 * e + 1]}, (h16x2){x[2 * e], x[2 * e + 1]}, acc[m], false);
         }
     }
 #pragma unroll

@@ -252,3 +252,25 @@ def test_no_kernel_uses_packed_fp32_math(kernels):
             bad = sorted(set(re.findall(r"\bv_pk_\w+_f32\b", fn)))
             assert not bad, (head, bad)
     assert seen_ws == 12, seen_ws
+
+
+def test_skinny_linear_rows_share_one_instruction_sequence(kernels):
+    """Root cause of round 4's red GPU suite (test_cfg2_stream_batch_rows_are_independent, rel 2.06e-3 on an idle GPU): the rows of
+    the time-embedding GEMV are unrolled inside one thread, and hipcc gave row 0 a v_fma_mix_f32 chain and row 1 v_dot2c_f32_f16
+    once packed fp32 math was switched off -- two roundings of the same sum, so the stream-batch rows were no longer
+    interchangeable.  The kernel now spells the dot product out (misc.hip); this asserts every unrolled row got the same instructions:
+    4 v_dot2(c)_f32_f16 per row and 16-byte column piece, no other fp32 multiply-add in the loop."""
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    seen = {}
+    for co in kernels["__code_objects__"]:
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        for fn in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+            head = fn.split("\n", 1)[0]
+            m = re.search(r"skinny_linear_kernelILi(\d)E", head)
+            if not m or ".kd>" in head:          # (the kernel descriptors are symbols too)
+                continue
+            mm = int(m.group(1))
+            seen[mm] = (len(re.findall(r"\bv_dot2c?_f32_f16", fn)), sorted(set(re.findall(r"\bv_(?:fma_mix|mad_mix|fma|mac|fmac|mad)_\w+", fn))))
+    assert sorted(seen) == list(range(1, 9)), seen
+    for mm, (ndot, other) in seen.items():
+        assert ndot == 4 * mm and not other, (mm, ndot, other)
