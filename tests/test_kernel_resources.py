@@ -270,7 +270,7 @@ def test_skinny_linear_rows_share_one_instruction_sequence(kernels):
             if not m or ".kd>" in head:          # (the kernel descriptors are symbols too)
                 continue
             mm = int(m.group(1))
-            seen[mm] = (len(re.findall(r"\bv_dot2c?_f32_f16", fn)), sorted(set(re.findall(r"\bv_(?:fma_mix|mad_mix|fma|mac|fmac|mad)_\w+", fn))))
+            seen[mm] = (len(re.findall(r"\bv_dot2c?_f32_f16", fn)), sorted(set(re.findall(r"\bv_(?:fma_mix|mad_mix|fma|mac|fmac|mad)_\w*f(?:32|16)\w*", fn))))
     assert sorted(seen) == list(range(1, 9)), seen
     for mm, (ndot, other) in seen.items():
         assert ndot == 4 * mm and not other, (mm, ndot, other)
