@@ -128,6 +128,11 @@ class HipStreamingUNet:
             o = state_dict
             if (o.cfg, o.h, o.w, o.device) != (cfg, self.h, self.w, self.device):
                 raise ValueError("shared packed weights need the same configuration, latent size and device")
+            if (o.N, o.ws_levels) != (self.N, self.ws_levels):
+                # the packing depends on the stream batch too (which levels take the weight-streaming form, the per-shape skip
+                # list keyed by M = N T): forms chosen for another N would be missing / forced here (as _load_packed checks)
+                raise ValueError(f"shared packed weights were packed for denoising_steps_num = {o.N} (weight-streaming levels "
+                                 f"{o.ws_levels}), this instance has {self.N} ({self.ws_levels}): re-pack")
             self.W, self.temb_offsets, self.text_offsets = o.W, o.temb_offsets, o.text_offsets
             self.n_map_blocks, self.temb_total, self.text_total, self.text_kp = o.n_map_blocks, o.temb_total, o.text_total, o.text_kp
         elif isinstance(state_dict, (str, os.PathLike)):
@@ -245,17 +250,32 @@ class HipStreamingUNet:
         def conv3ws(name, lvl):
             """resnet 3x3 conv: weight-streaming packing at the few-token levels, else the implicit-GEMM / patch-conv packing"""
             cw = sd[name + ".weight"]
-            if cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0 and ws_ok(name + ".weight", lvl, taps=9):
+            # (the kernel's loader walks 8 NL pixels per DMA instruction with at most two row wraps: W >= 8, wsgemm.hip; narrower
+            # levels -- tall / narrow latents such as 64 x 32 -- stay on the implicit-GEMM / patch kernels like in round 3)
+            if (lvl is not None and (self.w >> lvl) >= 8 and cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0
+                    and ws_ok(name + ".weight", lvl, taps=9)):
                 W[name + ".ww"] = ops.pack_wsgemm_conv3x3(g(name + ".weight"))
                 W[name + ".b"] = ops.f32(g(name + ".bias"))
             else:
                 conv3(name)
 
+        def concat_parts_ok(name):
+            """wsgemm takes whole 64-channel chunks from EACH input of a two-pointer concat (up blocks: hidden | skip)"""
+            cout, cin = sd[name + ".conv_shortcut.weight"].shape[:2]
+            if not name.startswith("up_blocks"):
+                return True                                   # one input
+            i, j = int(name.split(".")[1]), int(name.split(".")[3])
+            if j > 0:
+                c1 = cout
+            else:
+                c1 = sd[f"up_blocks.{i - 1}.resnets.0.conv1.weight" if i > 0 else "mid_block.resnets.0.conv1.weight"].shape[0]
+            return c1 % 64 == 0 and (cin - c1) % 64 == 0
+
         def resnet(name):
             lvl = level_of(name)
             norm(name + ".norm1"); conv3ws(name + ".conv1", lvl); norm(name + ".norm2"); conv3ws(name + ".conv2", lvl)
             if (name + ".conv_shortcut.weight") in sd:        # (two-input concat GEMM)
-                if ws_ok(name + ".conv_shortcut.weight", lvl):
+                if ws_ok(name + ".conv_shortcut.weight", lvl) and concat_parts_ok(name):
                     lin(name + ".conv_shortcut", lvl=lvl)
                 else:
                     W[name + ".conv_shortcut.w"] = ops.pack_linear(g(name + ".conv_shortcut.weight"))

@@ -209,10 +209,14 @@ def test_sd15_width_other_baseline_configs(golden, sd15_weights, name, h, w, N, 
     ("cfg-2: 512x512, N = 2, L = 16 (3.04 GB of KV cache)", 64, 64, 2, 16, 8),
     ("cfg-3: 768x512, N = 2, L = 24 (6.84 GB)", 64, 96, 2, 24, 8),
     ("cfg-5: 1024x576, N = 2, L = 40 (17.1 GB)", 72, 128, 2, 40, 8),
+    ("cfg-4: 512x512, N = 4, L = 16 (6.08 GB)", 64, 64, 4, 16, 8),
+    ("cfg-1: 256x256, N = 1, L = 4 sink + 8 rolling (0.29 GB)", 32, 32, 1, 12, 4),
 ])
 def test_full_size_frame_against_oracle(sd15_weights, name, h, w, N, L, S):
-    """BASELINE configs[1], [2] and [4] at FULL size (SD-1.5 widths, the latent, window and cache sizes the numbers are quoted
-    on): two streaming frames on pre-filled N(0,1) caches with the steady-state ring buffer, against the fp32 oracle on the same
+    """All five BASELINE configs at FULL size (SD-1.5 widths, the latent, window and cache sizes the numbers are quoted on -- and
+    the sizes the tuned schedule tables are keyed on, so every table entry the bench of a config uses is parity-checked here;
+    cfg-4: t_index_list [25, 31, 37, 43] of configs/toonyou.yaml:10; cfg-1: N = 1 with the build's own row-0 rule):
+    two streaming frames on pre-filled N(0,1) caches with the steady-state ring buffer, against the fp32 oracle on the same
     weights, inputs and caches (the oracle needs ~7 / ~11 / ~30 s per frame on 32 host threads, bench.py `cpu_baseline`).
     Checks the eps-prediction of both frames and, in every one of the 40 caches, the slot the frame wrote."""
     from live2diff_amd.config import sd15_config
@@ -234,7 +238,7 @@ def test_full_size_frame_against_oracle(sd15_weights, name, h, w, N, L, S):
     for _ in range(cfg.window_size + 5):
         ring_buffer_update(*rb, cfg.window_size, cfg.sink_size)
     enc = torch.randn(N, 77, cfg.cross_attention_dim, generator=g).half()
-    ts = torch.tensor([399, 199])
+    ts = torch.tensor({1: [399], 2: [399, 199], 4: [499, 379, 259, 139]}[N])
     rep = []
     for f in range(2):
         x, d = torch.randn(N, 4, 1, h, w, generator=g).half(), torch.randn(N, 4, 1, h, w, generator=g).half()

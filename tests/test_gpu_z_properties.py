@@ -101,6 +101,50 @@ def test_cfg2_stream_batch_rows_are_independent(cfg2_unet):
         c.copy_(b)
 
 
+def test_cfg2_frames_do_not_depend_on_what_the_previous_frame_left_behind(cfg2_unet):
+    """A, B, A, B on ONE instance with two DIFFERENT inputs / cache contents: the outputs and caches of the two A frames (and of
+    the two B frames) are bit-identical -- nothing a frame reads was left by the frame before it (split-K slabs and arrival
+    counters, GroupNorm accumulators, LDS-staged statistics, arena buffers, the conditioning cache).  The identical-input repeat
+    test above cannot see such a dependence (stale data of an identical frame are the right data); here stale data are another
+    frame's.  In front of the second A / B frame every arena buffer of the plan -- activations and split-K workspaces -- is
+    filled with NaN bit patterns, so a read of anything the frame has not written itself poisons the output."""
+    unet, kv, i = cfg2_unet
+    before = [c.clone() for c in kv]
+    g = torch.Generator(device=DEV).manual_seed(99)
+    j = dict(i)
+    for k in ("x", "d", "enc"):
+        j[k] = torch.randn(i[k].shape, generator=g, device=DEV, dtype=torch.float16)
+    j["ts"] = torch.tensor([299, 99], device=DEV)
+    kv_b0 = [b.roll(5, dims=2) for b in before]
+    kv_b = [b.clone() for b in kv_b0]
+
+    def poison():
+        for t in unet._plans["stream"].arena.all:
+            t.view(torch.int16 if t.element_size() == 2 else torch.int32).fill_(-1)          # 0xFFFF / 0xFFFFFFFF: NaN
+
+    outs = []
+    for rnd_ in range(2):
+        for c, b in zip(kv, before):
+            c.copy_(b)
+        for c, b in zip(kv_b, kv_b0):
+            c.copy_(b)
+        if rnd_:
+            poison()
+        a = _step(unet, kv, i)
+        ca = [c.clone() for c in kv]
+        if rnd_:
+            poison()
+        b_ = _step(unet, kv_b, j)
+        outs.append((a, ca, b_, [c.clone() for c in kv_b]))
+    (a1, ca1, b1, cb1), (a2, ca2, b2, cb2) = outs
+    assert torch.isfinite(a2).all() and torch.isfinite(b2).all() and not torch.equal(a1, b1)
+    assert torch.equal(a1, a2), f"A frames differ: {rel(a2, a1):.3e}"
+    assert torch.equal(b1, b2), f"B frames differ: {rel(b2, b1):.3e}"
+    assert all(torch.equal(x, y) for x, y in zip(ca1, ca2)) and all(torch.equal(x, y) for x, y in zip(cb1, cb2)), "KV caches differ"
+    for c, b in zip(kv, before):
+        c.copy_(b)
+
+
 def test_cfg2_concurrent_streams_share_weights(cfg2_unet):
     """Serving mode: three more UNet instances built FROM the first one share its packed weights and own
     everything else (plan buffers, statistics accumulators, split-K counters, KV caches).  Four streams with different inputs

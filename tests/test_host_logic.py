@@ -178,7 +178,11 @@ def test_plan_validates_sd15_shapes(dry_run):
 
 
 @pytest.mark.parametrize("name,h,w,N,L,S", [("cfg-1", 32, 32, 1, 12, 4), ("cfg-3", 64, 96, 2, 24, 8), ("cfg-4", 64, 64, 4, 16, 8),
-                                             ("cfg-5", 72, 128, 2, 40, 8)])
+                                             ("cfg-5", 72, 128, 2, 40, 8),
+                                             # tall / narrow latents: level 3 is 8 x 4 / 16 x 4 pixels -- narrower than the 8 pixels the
+                                             # weight-streaming conv loader walks per DMA instruction (round-4 advisor finding: those
+                                             # plans failed to build with EINVAL); their 3x3 convs keep the round-3 kernels
+                                             ("tall 512x256", 64, 32, 2, 16, 8), ("wide 256x1024", 32, 128, 2, 16, 8)])
 def test_plan_validates_other_baseline_configs(dry_run, name, h, w, N, L, S):
     """The other BASELINE.json configurations at SD-1.5 widths: stream and warm-up plans build from the heuristic schedule
     (their shapes are not in the cfg-2 table: deep split-K at the 4x4 / 8x8 levels, long windows on the chunked temporal kernel,
@@ -473,6 +477,8 @@ def test_unet_instances_can_share_packed_weights(dry_run):
     assert n == len(u._plan("stream", u.prepare_cache(2)).pl)
     with pytest.raises(ValueError):
         HipStreamingUNet(u, cfg, 8, 8, 2, device="cpu")
+    with pytest.raises(ValueError):                       # the packing depends on the stream batch too (weight-streaming levels, skip list)
+        HipStreamingUNet(u, cfg, 16, 16, 8, device="cpu")
     with pytest.raises(ValueError):
         HipStreamingUNet(u, tiny_config(window_size=12, sink_size=4), 16, 16, 2, device="cpu")
 
