@@ -603,19 +603,23 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))      # (the ring build of the flash op is traced under its own kernel name)
             traffic = (tj.get(name) or tj.get({"flash_attn_kernel": "flash_ring_kernel"}.get(name, name)) or {}).get("hbm_bytes_per_launch")
-        tsrc = ("static: profiles/traffic.json = rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
-                "not collected inside this run") if traffic is not None else None
+        tmeta = (tj.get("_meta") or {}) if os.path.exists(tpath) else {}
+        tsrc = (f"static: profiles/traffic.json, collected in round {tmeta.get('round', '?')} with rocprofv3 FETCH_SIZE / WRITE_SIZE passes over "
+                "the same plan (tools/traffic_frame.py), not inside this run") if traffic is not None else None
         if name in MFMA_KERNELS:
             ach = r["flops"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e12
             result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                                  "traffic_round": tmeta.get("round"),
                                   "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
+                                  "traffic_over_algorithmic": (round(traffic / (r["bytes"] / r["launches"]), 2) if traffic else None),
                                   "note": "dominant kernel family by time; the figure comparable with the single igemm family of rounds 1-2 "
                                           "is roofline_gemm_kernels (igemm + rowgemm + pconv + wsgemm)"}
         else:
             ach = r["bytes"] / r["launches"] / (r["avg_us"] * 1e-6) / 1e9
             result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS,
-                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc}
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                                  "traffic_round": tmeta.get("round")}
         my_frac = result["roofline"]["frac"]
         # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
         # rate is the figure comparable with the single igemm family of rounds 1-2
