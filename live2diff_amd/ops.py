@@ -465,7 +465,7 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
 
 def _load_ws_tuned():
     import json
-    path = os.path.join(os.path.dirname(__file__), "wsgemm_tuned.json")
+    path = os.environ.get("L2D_WSGEMM_TABLE") or os.path.join(os.path.dirname(__file__), "wsgemm_tuned.json")   # (override: A/B runs of tools)
     if os.environ.get("L2D_WSGEMM_NO_TABLE") or not os.path.exists(path):
         return {}, set()
     with open(path) as f:

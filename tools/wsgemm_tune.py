@@ -27,7 +27,11 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=os.path.join(ROOT, "live2diff_amd", "wsgemm_tuned.json"))
     ap.add_argument("--report", default="")
+    ap.add_argument("--max-m", type=int, default=0, help="offer the weight-streaming packing to levels of up to this many stream tokens "
+                                                         "(L2D_WSGEMM_MAX_M; default: the product's)")
     args = ap.parse_args()
+    if args.max_m:
+        os.environ["L2D_WSGEMM_MAX_M"] = str(args.max_m)
     from live2diff_amd import _lib, ops
     from live2diff_amd.config import sd15_config
     from live2diff_amd.unet_hip import HipStreamingUNet
@@ -83,6 +87,8 @@ def main():
             old[ops.wsgemm_key(i[0], i[13], i[0] * (i[1] + i[2]), i[14], 0, 1 if i[19] == 1 else 0, 0)].append(us0[j])
         elif op.kind == _lib.OP_ROWGEMM and i[7] != 2:
             old[ops.wsgemm_key(1, i[0], i[1], i[2], i[15] * 32, i[6], i[7])].append(us0[j])
+        elif op.kind == _lib.OP_PCONV and i[19] == 0:          # the patch-resident 3x3 conv (levels 0 / 1 at the SD resolutions)
+            old[ops.wsgemm_key(9, i[6] * i[7] * i[8], 9 * (i[1] + i[2]), i[14], 0, 0, 0)].append(us0[j])
     old = {k: sum(v) / len(v) for k, v in old.items()}
     del unet0, st0
     base, counts, frame0 = measure(None)
