@@ -467,13 +467,16 @@ def _load_ws_tuned():
     import json
     path = os.environ.get("L2D_WSGEMM_TABLE") or os.path.join(os.path.dirname(__file__), "wsgemm_tuned.json")   # (override: A/B runs of tools)
     if os.environ.get("L2D_WSGEMM_NO_TABLE") or not os.path.exists(path):
-        return {}, set()
+        return {}, set(), set()
     with open(path) as f:
         d = json.load(f)
-    return d["shapes"], set(d.get("skip", []))
+    return d["shapes"], set(d.get("skip", [])), set(d.get("large", []))
 
 
-_WS_TUNED, _WS_SKIP = _load_ws_tuned()
+# shapes -> schedule; skip = few-token shapes (M <= WS_SMALL_M) where the round-3 kernel measured faster; large = shapes with MORE
+# tokens where the weight-streaming kernel measured faster (there the round-3 kernels are the default: opt-in, not opt-out)
+_WS_TUNED, _WS_SKIP, _WS_LARGE = _load_ws_tuned() if not os.environ.get("L2D_WSGEMM_NO_TABLE") else ({}, set(), set())
+WS_SMALL_M = 1280
 
 
 def wsgemm_key(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0) -> str:
@@ -481,9 +484,14 @@ def wsgemm_key(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int =
 
 
 def wsgemm_wanted(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0) -> bool:
-    """False for the shapes where the in-frame tuner measured the round-3 kernel (igemm / rowgemm) faster than the best wsgemm
-    schedule (`skip` list of wsgemm_tuned.json, tools/wsgemm_tune.py): the packer then keeps the old form for that layer."""
-    return wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro) not in _WS_SKIP
+    """Few-token shapes (M <= 1280): True unless the in-frame tuner measured the round-3 kernel (igemm / rowgemm) faster than the best
+    wsgemm schedule (`skip` list of wsgemm_tuned.json, tools/wsgemm_tune.py).  Shapes with more tokens (round 5: level 1 of the
+    BASELINE configs, 2048-4608 tokens): True only where the tuner measured the weight-streaming kernel faster (`large` list) --
+    an untuned resolution keeps the round-3 kernels there.  The packer follows this."""
+    key = wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro)
+    if M > WS_SMALL_M and not os.environ.get("L2D_WSGEMM_LARGE_ALL"):      # (LARGE_ALL: the tuner offers every shape and measures)
+        return key in _WS_LARGE
+    return key not in _WS_SKIP
 
 
 def wsgemm_sizes(M: int, Nout: int, NW: int, NT: int, S: int):

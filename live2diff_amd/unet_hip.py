@@ -121,7 +121,8 @@ class HipStreamingUNet:
         # levels whose stream batch is small enough for the weight-streaming GEMM (wsgemm.hip): N * T tokens <= L2D_WSGEMM_MAX_M and
         # samples made of whole 32-token tiles.  Decides the PACKING of those levels' layers (and with it the plan's kernels).
         ws_on = os.environ.get("L2D_WSGEMM", "1") != "0"             # A/B knob: 0 = the round-3 kernels everywhere
-        ws_max = int(os.environ.get("L2D_WSGEMM_MAX_M", "1280"))
+        # (levels of up to 1280 tokens take it by default, larger ones -- up to this bound -- per measured shape: ops.wsgemm_wanted)
+        ws_max = int(os.environ.get("L2D_WSGEMM_MAX_M", "4608"))
         self.ws_levels = [ws_on and denoising_steps_num * (height >> l) * (width >> l) <= ws_max and ((height >> l) * (width >> l)) % 32 == 0
                           for l in range(cfg.num_levels)]
         if isinstance(state_dict, HipStreamingUNet):
@@ -440,7 +441,7 @@ class HipStreamingUNet:
         nl = self.cfg.num_levels
         return dict(ws_levels=[bool(v) for v in self.ws_levels],
                     old_levels=[((self.h >> l) * (self.w >> l)) % 32 != 0 for l in range(nl)],
-                    ws_skip=sorted(ops._WS_SKIP), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
+                    ws_skip=sorted(ops._WS_SKIP), ws_large=sorted(ops._WS_LARGE), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
                     rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
                     rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))
 

@@ -32,6 +32,7 @@ def main():
     args = ap.parse_args()
     if args.max_m:
         os.environ["L2D_WSGEMM_MAX_M"] = str(args.max_m)
+    os.environ["L2D_WSGEMM_LARGE_ALL"] = "1"          # offer the packing to every shape of the levels it may serve; the lists below decide
     from live2diff_amd import _lib, ops
     from live2diff_amd.config import sd15_config
     from live2diff_amd.unet_hip import HipStreamingUNet
@@ -70,6 +71,7 @@ def main():
 
     ops._WS_TUNED.clear()                      # measure against the cost model, not against an older table
     ops._WS_SKIP.clear()
+    ops._WS_LARGE.clear()
     # ---- the round-3 kernels on the same layers (a second instance packed without wsgemm): in-frame time per shape key
     os.environ["L2D_WSGEMM"] = "0"
     unet0 = HipStreamingUNet(device_random_state_dict(cfg, dev), cfg, h, w, N, device=dev)
@@ -104,7 +106,7 @@ def main():
                         continue                 # (the forced schedule did not fit this shape: it ran with its default)
                     if t < best[key][0]:
                         best[key] = (t, sched)
-    table, skip = {}, []
+    table, skip, large = {}, [], []
     n_per_key = collections.Counter()
     for (key, _s), c in counts.items():
         n_per_key[key] += c
@@ -116,6 +118,14 @@ def main():
         worse = t_old is not None and t_old < 0.97 * t
         lines.append(f"{key:40s} x{n_per_key[key]:3d}  default {s0} {t0:6.1f} us   best {sched} {t:6.1f} us {'*' if keep else ' '}"
                      f"   round-3 kernel {t_old if t_old is not None else float('nan'):6.1f} us {'-> skip' if worse else ''}")
+        big = int(key.split(",")[1]) > ops.WS_SMALL_M
+        if big:
+            # more tokens than the few-token levels: opt-in.  The weight-streaming form must be >= 3 % faster than the round-3 kernel
+            if t_old is not None and t < 0.97 * t_old:
+                large.append(key)
+                table[key] = list(sched)
+                lines[-1] += " -> large"
+            continue
         if worse:
             skip.append(key)
         if keep:
@@ -123,18 +133,20 @@ def main():
             gain += (t0 - t) * n_per_key[key]
     lines.append(f"expected gain {gain / 1e3:.3f} ms per frame over the default schedules")
     os.environ.pop("L2D_WSGEMM_FORCE", None)
-    prev, prev_skip = {}, []
+    prev, prev_skip, prev_large = {}, [], []
     if os.path.exists(args.out):
         d_ = json.load(open(args.out))
-        prev, prev_skip = d_.get("shapes", {}), d_.get("skip", [])
+        prev, prev_skip, prev_large = d_.get("shapes", {}), d_.get("skip", []), d_.get("large", [])
     measured = set(best)
     prev = {k: v for k, v in prev.items() if k not in measured}       # (a shape measured now loses its older pick)
     prev.update(table)
     prev_skip = sorted((set(prev_skip) - measured) | set(skip))
+    prev_large = sorted((set(prev_large) - measured) | set(large))
     with open(args.out, "w") as f:
         json.dump({"note": "in-frame picks of tools/wsgemm_tune.py: key = taps,M,Ktot,Nout,ntr,epi,pro -> [NW, NT, NL, S]; skip = shapes "
-                           "where the round-3 kernel (igemm / rowgemm) measured >= 3 % faster in the frame: the packer keeps its form",
-                   "shapes": prev, "skip": prev_skip}, f, indent=1, sort_keys=True)
+                           "where the round-3 kernel (igemm / rowgemm) measured >= 3 % faster in the frame: the packer keeps its form"
+                           "; large = shapes with more than 1280 tokens where wsgemm measured >= 3 % faster than the round-3 kernel (opt-in)",
+                   "shapes": prev, "skip": prev_skip, "large": prev_large}, f, indent=1, sort_keys=True)
     print("\n".join(lines))
     if args.report:
         open(args.report, "w").write("\n".join(lines) + "\n")
