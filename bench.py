@@ -448,9 +448,19 @@ def main():
         sd_cpu = random_state_dict(cfg, dtype=torch.float16) if need_cpu_weights else device_random_state_dict(cfg, dev)
     else:
         sd_cpu = None
-    sd = parallel.broadcast_state_dict(spec, sd_cpu, dev)
-    unet = HipStreamingUNet(sd, cfg, h, w, N, device=dev, use_graph=bool(args.graph), tattn_variant=args.tattn_variant)
-    del sd
+    if world > 1:
+        # rank 0 packs ONCE and the PACKED weights are replicated (scatter + all-gather over all xGMI links, checksum);
+        # the other ranks build their instance from what they received -- no packing pass, no raw state dict there
+        unet0 = (HipStreamingUNet(sd_cpu, cfg, h, w, N, device=dev, use_graph=bool(args.graph), tattn_variant=args.tattn_variant)
+                 if rank == 0 else None)
+        packed = parallel.replicate_packed_weights(unet0, dev)
+        unet = unet0 if rank == 0 else HipStreamingUNet(packed, cfg, h, w, N, device=dev, use_graph=bool(args.graph),
+                                                        tattn_variant=args.tattn_variant)
+        del packed
+    else:
+        sd = parallel.broadcast_state_dict(spec, sd_cpu, dev)
+        unet = HipStreamingUNet(sd, cfg, h, w, N, device=dev, use_graph=bool(args.graph), tattn_variant=args.tattn_variant)
+        del sd
     kv = unet.prepare_cache(N)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     for c in kv:

@@ -2,8 +2,9 @@
 
 The reference has no distributed path at all.  Streams share nothing per frame --
 weights are read-only replicas, KV-cache / latent buffers / ring indices are private -- so the only
-collectives are (a) a one-time RCCL replication of the fp16 weights from rank 0, done as scatter (1/G shard per
-peer, one xGMI link each) + all-gather (all links), in a few flat 1 GB buckets, with an all-reduced checksum,
+collectives are (a) a one-time RCCL replication of the PACKED weights from rank 0 (which runs the packing pass once;
+replicate_packed_weights), done as scatter (1/G shard per peer, one xGMI link each) + all-gather (all links), in a few flat
+1 GB buckets, with an all-reduced checksum (broadcast_state_dict does the same for a raw fp16 state dict),
 and (b) the barrier / max / all-gather of per-rank results around the timed region of the benchmark.  Nothing on
 the per-frame path.
 
@@ -95,6 +96,73 @@ def broadcast_state_dict(spec: Dict[str, tuple], sd: Optional[Dict[str, torch.Te
     if not torch.equal(lo, hi):
         raise RuntimeError(f"weight broadcast checksum mismatch across ranks: {lo.item()} vs {hi.item()}")
     return out
+
+
+def replicate_tensors(tensors: Optional[Dict[str, torch.Tensor]], device, src: int = 0, bucket_bytes: int = 1 << 30,
+                      force_collectives: bool = False) -> Dict[str, torch.Tensor]:
+    """Rank `src` holds `tensors` (any dtypes: the PACKED weights are fp16 matrices, fp32 biases / column sums); every rank returns
+    a full copy on `device`.  Names, shapes and dtypes travel as one small object broadcast; the payload as raw bytes, every tensor
+    at a 16-byte aligned offset of a flat uint8 bucket of up to `bucket_bytes`, each bucket through the same scatter (1/G shard per
+    peer, one xGMI link each) + all-gather (all links) as broadcast_state_dict, verified by the same position-weighted checksum
+    (over the bytes), all-reduced MIN / MAX."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1 and not (force_collectives and dist.is_initialized()):
+        return {k: v.to(device) for k, v in tensors.items()}
+    box = [[(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in tensors.items()] if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    items = box[0]
+    size = lambda shp, dt: (_numel(shp) * torch.empty(0, dtype=getattr(torch, dt)).element_size() + 15) // 16 * 16
+    out: Dict[str, torch.Tensor] = {}
+    checksum = torch.zeros(1, dtype=torch.float64, device=device)
+    i = 0
+    while i < len(items):
+        j, n = i, 0
+        while j < len(items) and (n == 0 or n + size(items[j][1], items[j][2]) <= bucket_bytes):
+            n += size(items[j][1], items[j][2])
+            j += 1
+        shard = ((n + world - 1) // world + 15) // 16 * 16
+        flat = torch.empty(shard * world, dtype=torch.uint8, device=device)
+        if rank == src:
+            flat.zero_()
+            off = 0
+            for k, shp, dt in items[i:j]:
+                t = tensors[k].to(device).contiguous().reshape(-1).view(torch.uint8)
+                flat[off:off + t.numel()].copy_(t)
+                off += size(shp, dt)
+        mine = torch.empty(shard, dtype=torch.uint8, device=device)
+        dist.scatter(mine, scatter_list=(list(flat.view(world, shard).unbind(0)) if rank == src else None), src=src)
+        _all_gather_flat(flat, mine, world, shard)
+        checksum += _checksum(flat, n)
+        off = 0
+        for k, shp, dt in items[i:j]:
+            nb = _numel(shp) * torch.empty(0, dtype=getattr(torch, dt)).element_size()
+            out[k] = flat[off:off + nb].view(getattr(torch, dt)).view(shp)
+            off += size(shp, dt)
+        i = j
+    lo, hi = checksum.clone(), checksum.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"packed-weight replication checksum mismatch across ranks: {lo.item()} vs {hi.item()}")
+    return out
+
+
+def replicate_packed_weights(unet_or_none, device, src: int = 0, force_collectives: bool = False):
+    """"one-time RCCL broadcast of PACKED fp16 weights".  Rank `src` passes its HipStreamingUNet (it packed the state
+    dict once); every rank gets a `PackedWeights` to construct its own instance from (`HipStreamingUNet(packed, cfg, h, w, N)`) --
+    no rank but `src` runs the packing pass.  Rank `src` gets its own tensors back untouched."""
+    from .unet_hip import PackedWeights
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1 and not (force_collectives and dist.is_initialized()):
+        return unet_or_none.packed_state()
+    box = [unet_or_none._packed_meta() if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    W = replicate_tensors(unet_or_none.W if rank == src else None, device, src=src, force_collectives=force_collectives)
+    if rank == src:
+        return unet_or_none.packed_state()
+    return PackedWeights(W, box[0])
 
 
 _CK_CHUNK = 1 << 24

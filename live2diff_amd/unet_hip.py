@@ -92,6 +92,16 @@ class _Act:
         self.buf, self.C, self.H, self.W, self.producer = buf, C, H, W, producer
 
 
+class PackedWeights:
+    """Packed weights outside an instance: `W` (name -> device tensor, what `_pack_weights` produced) + `meta` (the strings a
+    packed-weight file carries).  Produced by `HipStreamingUNet.packed_state()`, accepted by the constructor -- the unit of the
+    multi-GPU weight replication (parallel.replicate_packed_weights: rank 0 packs once, every rank receives the packed tensors)."""
+    __slots__ = ("W", "meta")
+
+    def __init__(self, W, meta):
+        self.W, self.meta = W, meta
+
+
 class HipStreamingUNet:
     def __init__(self, state_dict, cfg: UNetConfig, height: int, width: int,
                  denoising_steps_num: int, device="cuda", warmup_frames: Optional[int] = None, use_graph: bool = False,
@@ -138,6 +148,8 @@ class HipStreamingUNet:
             self.n_map_blocks, self.temb_total, self.text_total, self.text_kp = o.n_map_blocks, o.temb_total, o.text_total, o.text_kp
         elif isinstance(state_dict, (str, os.PathLike)):
             self._load_packed(state_dict)          # a file written by save_packed(): skips the packing pass
+        elif isinstance(state_dict, PackedWeights):
+            self._adopt_packed(state_dict.W, state_dict.meta, "packed weights")     # received from another rank
         else:
             self._pack_weights(state_dict)
         self._plans = {}
@@ -402,14 +414,19 @@ class HipStreamingUNet:
         weight-streaming forms, levels whose samples are not whole 32-token tiles the implicit-GEMM forms, and the L2D_ROWGEMM*
         knobs move layers between kernels.  The file records all of that; `_load_packed` refuses a file packed for another layout
         with a "re-pack" error instead of failing on a missing tensor later."""
-        import json
-
         from safetensors.torch import save_file
-        meta = dict(format=str(self.PACK_FORMAT), abi=str(_lib.ABI_VERSION), window=str(self.cfg.window_size),
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.W.items()}, str(path), metadata=self._packed_meta())
+
+    def _packed_meta(self) -> dict:
+        import json
+        return dict(format=str(self.PACK_FORMAT), abi=str(_lib.ABI_VERSION), window=str(self.cfg.window_size),
                     block_out_channels=json.dumps(list(self.cfg.block_out_channels)),
                     temb_offsets=json.dumps(self.temb_offsets), text_offsets=json.dumps(self.text_offsets),
                     n_map_blocks=str(self.n_map_blocks), layout=json.dumps(self._pack_layout()))
-        save_file({k: v.detach().cpu().contiguous() for k, v in self.W.items()}, str(path), metadata=meta)
+
+    def packed_state(self) -> "PackedWeights":
+        """The packed weights of this instance as (tensors, metadata) -- what a packed-weight file holds, without the file."""
+        return PackedWeights(self.W, self._packed_meta())
 
     def _load_packed(self, path) -> None:
         import json
@@ -417,19 +434,30 @@ class HipStreamingUNet:
         from safetensors import safe_open
         with safe_open(str(path), framework="pt", device="cpu") as f:
             meta = f.metadata() or {}
-            if int(meta.get("format", -1)) != self.PACK_FORMAT or int(meta.get("abi", -1)) != _lib.ABI_VERSION:
-                raise ValueError(f"{path}: packed-weight format {meta.get('format')} / ABI {meta.get('abi')} does not match "
-                                 f"this build ({self.PACK_FORMAT} / {_lib.ABI_VERSION}): re-pack from the state dict")
-            if json.loads(meta.get("layout", "null")) != self._pack_layout():
-                raise ValueError(f"{path}: packed for kernel layout {meta.get('layout')}, this instance needs {json.dumps(self._pack_layout())} "
-                                 "(latent size / denoising steps / L2D_ROWGEMM* / L2D_WSGEMM* differ): re-pack from the state dict")
-            if int(meta["window"]) != self.cfg.window_size or json.loads(meta["block_out_channels"]) != list(self.cfg.block_out_channels):
-                raise ValueError(f"{path}: packed for window {meta['window']} / widths {meta['block_out_channels']}, "
-                                 f"this instance is window {self.cfg.window_size} / {list(self.cfg.block_out_channels)}")
+            self._check_packed_meta(meta, path)
             # (a copy in every case: on the CPU -- dry-run plans of the test-suite -- get_tensor() returns a view into the file buffer
             #  whose address need not be 16-byte aligned, which the launch validation requires of every pointer)
-            self.W = {k: (f.get_tensor(k).to(self.device) if torch.device(self.device).type != "cpu" else f.get_tensor(k).clone())
-                      for k in f.keys()}
+            W = {k: (f.get_tensor(k).to(self.device) if torch.device(self.device).type != "cpu" else f.get_tensor(k).clone())
+                 for k in f.keys()}
+        self._adopt_packed(W, meta, path, checked=True)
+
+    def _check_packed_meta(self, meta, path) -> None:
+        import json
+        if int(meta.get("format", -1)) != self.PACK_FORMAT or int(meta.get("abi", -1)) != _lib.ABI_VERSION:
+            raise ValueError(f"{path}: packed-weight format {meta.get('format')} / ABI {meta.get('abi')} does not match "
+                             f"this build ({self.PACK_FORMAT} / {_lib.ABI_VERSION}): re-pack from the state dict")
+        if json.loads(meta.get("layout", "null")) != self._pack_layout():
+            raise ValueError(f"{path}: packed for kernel layout {meta.get('layout')}, this instance needs {json.dumps(self._pack_layout())} "
+                             "(latent size / denoising steps / L2D_ROWGEMM* / L2D_WSGEMM* differ): re-pack from the state dict")
+        if int(meta["window"]) != self.cfg.window_size or json.loads(meta["block_out_channels"]) != list(self.cfg.block_out_channels):
+            raise ValueError(f"{path}: packed for window {meta['window']} / widths {meta['block_out_channels']}, "
+                             f"this instance is window {self.cfg.window_size} / {list(self.cfg.block_out_channels)}")
+
+    def _adopt_packed(self, W, meta, path, checked: bool = False) -> None:
+        import json
+        if not checked:
+            self._check_packed_meta(meta, path)
+        self.W = W
         self.temb_offsets = {k: int(v) for k, v in json.loads(meta["temb_offsets"]).items()}
         self.text_offsets = {k: int(v) for k, v in json.loads(meta["text_offsets"]).items()}
         self.n_map_blocks = int(meta["n_map_blocks"])

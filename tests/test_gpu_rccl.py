@@ -33,6 +33,31 @@ WORKER = textwrap.dedent("""
         assert set(out) == set(sd)
         for k in sd:
             assert out[k].is_cuda and torch.equal(out[k].cpu(), sd[k]), (algo, k)
+    # the PACKED-weight replication (what bench.py --gpus N uses): object broadcast of the metadata, uint8 scatter + all-gather of
+    # mixed fp16 / fp32 tensors, byte checksum -- through RCCL with device tensors; the replica builds a working instance
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    cfg2 = tiny_config(channels=(64, 128, 128, 128), cross_attention_dim=64)
+    sd2 = {k: v.cuda() for k, v in random_state_dict(cfg2, dtype=torch.float16).items()}
+    u0 = HipStreamingUNet(sd2, cfg2, 16, 16, 2)
+    W = parallel.replicate_tensors(u0.W, "cuda", bucket_bytes=3_000_001, force_collectives=True)
+    assert set(W) == set(u0.W) and all(W[k].is_cuda and W[k].dtype == u0.W[k].dtype and torch.equal(W[k], u0.W[k]) for k in W)
+    assert all(W[k].data_ptr() % 16 == 0 for k in W)
+    from live2diff_amd.unet_hip import PackedWeights
+    u1 = HipStreamingUNet(PackedWeights(W, u0._packed_meta()), cfg2, 16, 16, 2)
+    kv0, kv1 = u0.prepare_cache(2), u1.prepare_cache(2)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rn = lambda *s_: torch.randn(*s_, generator=g, device="cuda", dtype=torch.float16)
+    for c0, c1 in zip(kv0, kv1):
+        c0.normal_(generator=g); c1.copy_(c0)
+    from live2diff_amd.pipeline_stream_animation_depth import ring_buffer_init
+    rb = ring_buffer_init(2, cfg2.window_size, cfg2.sink_size)
+    args = dict(encoder_hidden_states=rn(2, 77, 64), temporal_attention_mask=rb[0].half().cuda(), depth_sample=rn(2, 4, 1, 16, 16),
+                pe_idx=rb[1].cuda(), update_idx=rb[2].cuda())
+    x, ts = rn(2, 4, 1, 16, 16), torch.tensor([399, 199], device="cuda")
+    a = u0(x, ts, kv_cache=kv0, **args)["sample"].clone()
+    b = u1(x, ts, kv_cache=kv1, **args)["sample"].clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b), "an instance built from replicated packed weights must give the same frame"
     assert parallel.gather_floats(3.5, device="cuda") == [3.5]
     parallel.barrier()
     assert parallel.max_over_ranks(2.0, device="cuda") == 2.0 and parallel.sum_over_ranks(2.0, device="cuda") == 2.0

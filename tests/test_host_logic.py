@@ -312,8 +312,10 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     # (21 level-0 / level-1 3x3 convs: patch kernel; the levels with <= 512 stream tokens: weight-streaming GEMM where the in-frame
     #  tuner found it faster, round 4)
     gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV, _lib.OP_WSGEMM) if k_ in tot]
-    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 and tot[_lib.OP_PCONV][0] == 21
-    assert tot.get(_lib.OP_WSGEMM, [0])[0] >= 50
+    # (round 5: the level-1 3x3 convs whose contraction is long -- 9 of the 10 -- and the level-1 q | k | V^T / GEGLU layers moved to the
+    #  weight-streaming kernel too, per measured shape: the `large` list of wsgemm_tuned.json)
+    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 and tot[_lib.OP_PCONV][0] == 12
+    assert tot.get(_lib.OP_WSGEMM, [0])[0] >= 100
     assert abs(sum(g_[1] for g_ in gemm) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
     assert _lib.OP_LAYERNORM not in tot
 

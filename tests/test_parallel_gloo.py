@@ -1,5 +1,6 @@
-"""world_size-2 `gloo` test of the multi-GPU path (CPU): weight broadcast + checksum, barrier, the max / sum
-reductions around the timed region, and that two ranks driving independent streams keep independent state."""
+"""world_size-2 `gloo` test of the multi-GPU path (CPU): weight broadcast + checksum (raw state dict and PACKED weights: rank 0
+packs once, rank 1 builds its plan from the replicated packed tensors), barrier, the max / sum reductions around the timed
+region, and that two ranks driving independent streams keep independent state."""
 import os
 import socket
 import subprocess
@@ -26,6 +27,35 @@ WORKER = textwrap.dedent("""
         assert set(out) == set(ref)
         for k in ref:
             assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), (algo, k)
+    # SURVEY 8e as written: rank 0 packs ONCE, the PACKED weights (fp16 matrices + fp32 biases / column sums) are replicated, rank 1
+    # builds its instance from what it received -- no packing pass there -- and both ranks hold identical packed tensors and plans
+    from live2diff_amd import _lib
+    from live2diff_amd.unet_hip import HipStreamingUNet, PackedWeights
+    _lib.set_dry_run(True)
+    cfg = tiny_config()                                                    # (the widths the dry-run plan tests use)
+    ref = random_state_dict(cfg, dtype=torch.float16)
+    u0 = HipStreamingUNet(ref, cfg, 16, 16, 2, device="cpu") if rank == 0 else None
+    packed = parallel.replicate_packed_weights(u0, "cpu")
+    assert isinstance(packed, PackedWeights)
+    calls = []
+    orig = HipStreamingUNet._pack_weights
+    HipStreamingUNet._pack_weights = lambda self, sd_: calls.append(1) or orig(self, sd_)
+    u = u0 if rank == 0 else HipStreamingUNet(packed, cfg, 16, 16, 2, device="cpu")
+    assert not calls, "a receiving rank must not run the packing pass"
+    mine = HipStreamingUNet(ref, cfg, 16, 16, 2, device="cpu")          # (what this rank WOULD have packed itself)
+    assert set(u.W) == set(mine.W)
+    for k in mine.W:
+        assert u.W[k].dtype == mine.W[k].dtype and torch.equal(u.W[k], mine.W[k]), k
+    assert (u.temb_offsets, u.text_offsets, u.n_map_blocks, u.temb_total, u.text_total) == (mine.temb_offsets, mine.text_offsets, mine.n_map_blocks, mine.temb_total, mine.text_total)
+    st = u._plan("stream", u.prepare_cache(2))
+    st.pl.run(stream=0)                                                    # every op validates against the received tensors
+    assert len(st.pl) == len(mine._plan("stream", mine.prepare_cache(2)).pl)
+    try:
+        HipStreamingUNet(packed, cfg, 8, 8, 2, device="cpu")              # packed for another latent size: refused, not mis-used
+        raise SystemExit("a packed layout for another latent size was accepted")
+    except ValueError:
+        pass
+    _lib.set_dry_run(False)
     assert parallel.gather_floats(10.0 + rank) == [10.0, 11.0]
     # independent streams: rank r advances its ring buffer r+3 frames; states differ, nothing is shared
     rb = ring_buffer_init(2)
