@@ -20,10 +20,12 @@ DB=$(find /tmp/prof/kt -name "*.db" | head -1)
 python tools/rocpd_summary.py "$DB" "$OUT/${TAG}_bench_cfg2"
 python tools/frame_trace.py "$DB" "$OUT/plan.csv" "$OUT/${TAG}_frame_trace.csv" 2 | tee "$OUT/${TAG}_frame_trace_summary.txt"
 
-# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md), kernel-trace only
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md), kernel-trace only, over the FRAME REPLAY target
+# (tools/traffic_frame.py: the plan, three frames, nothing else -- round 4's passes over the whole bench.py died inside rocprofv3),
+# each pass under its own timeout
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c -d /tmp/prof/$c -o p -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --breakdown 0 \
-        > /dev/null 2> "$OUT/pmc_${c}_err.log"
+    ( cd /tmp && FRAMES=3 timeout 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof/$c -o p -- python "$OLDPWD/tools/traffic_frame.py" \
+        > "$OLDPWD/$OUT/pmc_${c}.log" 2>&1 ) || echo "PMC pass $c failed (see $OUT/pmc_${c}.log)"
 done
-python tools/pmc_summary.py "$OUT/${TAG}_pmc_bench.txt" $(find /tmp/prof/FETCH_SIZE /tmp/prof/WRITE_SIZE -name "*.db") --traffic "$OUT/traffic.json"
+python tools/pmc_summary.py "$OUT/${TAG}_pmc_frame.txt" $(find /tmp/prof/FETCH_SIZE /tmp/prof/WRITE_SIZE -name "*.db") --traffic "$OUT/traffic.json"
 cat "$OUT/traffic.json" | head -40
