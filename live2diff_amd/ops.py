@@ -475,7 +475,7 @@ def _load_ws_tuned():
 
 # shapes -> schedule; skip = few-token shapes (M <= WS_SMALL_M) where the round-3 kernel measured faster; large = shapes with MORE
 # tokens where the weight-streaming kernel measured faster (there the round-3 kernels are the default: opt-in, not opt-out)
-_WS_TUNED, _WS_SKIP, _WS_LARGE = _load_ws_tuned() if not os.environ.get("L2D_WSGEMM_NO_TABLE") else ({}, set(), set())
+_WS_TUNED, _WS_SKIP, _WS_LARGE = _load_ws_tuned()
 WS_SMALL_M = 1280
 
 

@@ -112,7 +112,8 @@ def replicate_tensors(tensors: Optional[Dict[str, torch.Tensor]], device, src: i
     box = [[(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in tensors.items()] if rank == src else None]
     dist.broadcast_object_list(box, src=src)
     items = box[0]
-    size = lambda shp, dt: (_numel(shp) * torch.empty(0, dtype=getattr(torch, dt)).element_size() + 15) // 16 * 16
+    esize = {dt: torch.empty(0, dtype=getattr(torch, dt)).element_size() for dt in {it[2] for it in items}}
+    size = lambda shp, dt: (_numel(shp) * esize[dt] + 15) // 16 * 16          # bytes of a tensor's slot in a bucket (16-byte aligned)
     out: Dict[str, torch.Tensor] = {}
     checksum = torch.zeros(1, dtype=torch.float64, device=device)
     i = 0
@@ -136,7 +137,7 @@ def replicate_tensors(tensors: Optional[Dict[str, torch.Tensor]], device, src: i
         checksum += _checksum(flat, n)
         off = 0
         for k, shp, dt in items[i:j]:
-            nb = _numel(shp) * torch.empty(0, dtype=getattr(torch, dt)).element_size()
+            nb = _numel(shp) * esize[dt]
             out[k] = flat[off:off + nb].view(getattr(torch, dt)).view(shp)
             off += size(shp, dt)
         i = j
