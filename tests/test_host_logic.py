@@ -541,3 +541,30 @@ def test_wsgemm_packers_schedule_and_validation(dry_run):
         op, keep = ops.wsgemm(x, wt, out, M=128, Nout=64, C1=64, ldx1=64, ldo=64, sched=(2, 1, 1, 1, False))
         op.i[20] = 1                                                                                            # LayerNorm fold without column sums
         validate((op, keep))
+
+
+def test_wsgemm_table_lists_are_consistent_and_gate_the_packing():
+    """wsgemm_tuned.json: `skip` (opt-out) holds few-token shapes only, `large` (opt-in, round 5) shapes above WS_SMALL_M only, every
+    schedule is one the launcher accepts for its shape; ops.wsgemm_wanted follows the lists: an UNTUNED shape is wanted below the
+    bound and not wanted above it (an unmeasured resolution keeps the round-3 kernels at its many-token levels)."""
+    import json
+
+    from live2diff_amd import ops
+    d = json.load(open(os.path.join(os.path.dirname(ops.__file__), "wsgemm_tuned.json")))
+    M_of = lambda k: int(k.split(",")[1])
+    assert d["large"] and all(M_of(k) > ops.WS_SMALL_M for k in d["large"]), "large = opt-in list of many-token shapes"
+    assert all(M_of(k) <= ops.WS_SMALL_M for k in d["skip"]), "skip = opt-out list of few-token shapes"
+    assert not set(d["large"]) & set(d["skip"])
+    for key, (nw, nt, nl, S) in d["shapes"].items():
+        taps, M, K, N, ntr, epi, pro = (int(v) for v in key.split(","))
+        tiles = N // 32
+        assert nt in (1, 2) and 1 <= nw <= (8 if nt == 1 else 4) and nl in (1, 2) and tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0, key
+        assert 1 <= S <= max(1, K // 64) and not (ntr and S > 1), key
+        assert ops.wsgemm_schedule(M, K, N, ntr, epi, pro, taps)[:4] == (nw, nt, nl, S), key
+    for key in d["large"]:
+        assert ops.wsgemm_wanted(*[int(v) for v in key.split(",")])
+    for key in d["skip"]:
+        assert not ops.wsgemm_wanted(*[int(v) for v in key.split(",")])
+    assert ops.wsgemm_wanted(1, 640, 1280, 1280)              # untuned, few tokens: the weight-streaming kernel
+    assert not ops.wsgemm_wanted(1, 2304, 1280, 1280)         # untuned, many tokens: the round-3 kernels
+    assert not ops.wsgemm_wanted(9, 8192, 2880, 320)          # level 0 of cfg-2: measured, lost
