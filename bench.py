@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
-MFMA_KERNELS = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel", "flash_attn_kernel")   # kernel families priced against the MFMA roofline
+MFMA_KERNELS = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel", "rowchain_kernel", "flash_attn_kernel")   # kernel families priced against the MFMA roofline
 
 
 # (height, width, denoise steps, window L) of the BASELINE.json configurations the GPU leg can run
@@ -58,6 +58,9 @@ def op_work(op, kinds):
     if k == kinds.OP_WSGEMM:
         taps, C, M, Nout = i[0], i[1] + i[2], i[13], i[14]
         return 2.0 * M * Nout * taps * C, 2.0 * (M * C + Nout * taps * C + M * (Nout // 2 if i[19] == 1 else Nout))
+    if k == kinds.OP_ROWCHAIN:
+        M, C = i[0], i[1]                 # to_out C x C, GEGLU C x 8C, FF2 4C x C, proj_out C x C; in: a, res1, res2; out
+        return 2.0 * M * 14 * C * C, 2.0 * (4 * M * C + 14 * C * C)
     if k == kinds.OP_FLASH_ATTN:
         B, H, d, Tq, Tk = i[0], i[1], i[2], i[3], i[4]
         return 4.0 * B * H * Tq * Tk * d, 2.0 * B * H * d * (2 * Tq + 2 * Tk)
@@ -78,7 +81,8 @@ def op_work(op, kinds):
 
 KIND_NAMES = {1: "igemm_kernel", 2: "gn_stats_kernel", 3: "gn_apply_kernel", 4: "layernorm_kernel", 5: "flash_attn_kernel",
               6: "tattn_stream_kernel", 7: "tattn_warmup_kernel", 8: "skinny_linear_kernel", 9: "timestep_embed_kernel",
-              10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy", 23: "rowgemm_kernel", 24: "pconv_kernel", 25: "wsgemm_kernel"}
+              10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy", 23: "rowgemm_kernel", 24: "pconv_kernel", 25: "wsgemm_kernel",
+              26: "rowchain_kernel"}
 
 
 def per_kernel_breakdown(unet, reps=5):
@@ -149,6 +153,8 @@ def op_dims(op, kinds):
         return f"M{i[0]} N{i[2]} K{i[1]} e{i[6]} p{i[7]} w{i[12]} t{i[13]} m{i[14]} tr{i[15]}"
     if op.kind == kinds.OP_WSGEMM:
         return f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} e{i[19]} p{i[20]} w{i[9]} t{i[10]} l{i[11]} S{max(1, i[12])} tr{i[21]} nt{i[23]}"
+    if op.kind == kinds.OP_ROWCHAIN:
+        return f"M{i[0]} C{i[1]}"
     if op.kind == kinds.OP_FLASH_ATTN:
         return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
     if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):
@@ -633,7 +639,7 @@ def main():
         my_frac = result["roofline"]["frac"]
         # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
         # rate is the figure comparable with the single igemm family of rounds 1-2
-        GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel")
+        GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel", "rowchain_kernel")
         gem = [rows[k_] for k_ in GEMM_FAMILIES if k_ in rows]
         if gem:
             gms, gfl = sum(g_["ms"] for g_ in gem), sum(g_["flops"] for g_ in gem)

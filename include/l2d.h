@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 4
+#define L2D_ABI_VERSION 5
 
 enum {
     L2D_OK = 0,
@@ -193,6 +193,16 @@ enum {
  *   out = rstd (acc - mean colsum) + bias with the row statistics taken in the kernel) i21 trailing weight tiles stored transposed
  *   i22 ldt i23 non-temporal weight loads (single row tile) i30 T tokens per sample (p8)   l0 elements between samples in p8
  *   f0 eps of the LayerNorm
+ *
+ * L2D_OP_ROWCHAIN  token-resident tail of a transformer block, ONE launch (rowchain.hip; reference attention.py:243-270,125-133;
+ *                motion_module.py:401-435,290-297):   h2 = to_out(a) + res1;  h3 = FF2(GEGLU(LayerNorm(h2))) + h2;
+ *                out = proj_out(h3) + res2.   C = 320 (the level whose M / 32 blocks fill the chip), M % 32 == 0.
+ *   p0 a [M][lda] half (attention output)   p1 res1 [M][ldr1] half (residual stream)   p2 res2 [M][ldr2] half (block input)
+ *   p3 out [M][ldo] half   p4 / p5 to_out weights (L2D_OP_ROWGEMM fragment order, ops.pack_rowgemm) / fp32 bias
+ *   p6 / p7 GEGLU projection (LayerNorm gamma / beta folded, value / gate rows interleaved as for L2D_OP_ROWGEMM epi 1) / bias
+ *   p8 / p11 FF2 weights / bias   p12 / p13 proj_out weights / bias   p9 / p10, i24..i29 GroupNorm statistics of `out` as
+ *   L2D_OP_IGEMM (T % 32 == 0)
+ *   i0 M i1 C i2 lda i3 ldr1 i4 ldr2 i5 ldo   f0 eps of the LayerNorm
  */
 enum {
     L2D_OP_IGEMM = 1,
@@ -220,6 +230,7 @@ enum {
     L2D_OP_ROWGEMM = 23,
     L2D_OP_PCONV = 24,
     L2D_OP_WSGEMM = 25,
+    L2D_OP_ROWCHAIN = 26,
 };
 
 typedef struct l2d_op {

@@ -200,7 +200,55 @@ def gn_target(op, acc_ptr: int, **kw) -> bool:
         return pconv_gn_target(op, acc_ptr, **kw)
     if op.kind == _lib.OP_WSGEMM:
         return wsgemm_gn_target(op, acc_ptr, **kw)
+    if op.kind == _lib.OP_ROWCHAIN:
+        return rowchain_gn_target(op, acc_ptr, **kw)
     return False
+
+
+def rowchain_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """The same request to a rowchain op (its row phase accumulates like the row GEMM's; a block is 32 tokens of one sample)."""
+    assert op.kind == _lib.OP_ROWCHAIN
+    if T % 32 or op.i[0] % T or G > 32 or (cpg | choff) & 1:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
+
+
+ROWCHAIN_C = 320                # the width the chain kernel is instantiated for (SD-1.5 level 0)
+ROWCHAIN_MIN_BLOCKS = 192       # M / 32 blocks must fill the chip: below this the four separate launches spread better
+
+
+def rowchain_ok(M: int, C: int, T: int) -> bool:
+    """Shapes the token-resident block tail (csrc/rowchain.hip) takes"""
+    return (os.environ.get("L2D_ROWCHAIN", "1") != "0" and C == ROWCHAIN_C and M % 32 == 0 and T % 32 == 0
+            and M // 32 >= ROWCHAIN_MIN_BLOCKS)
+
+
+def rowchain(a, res1, res2, out, *, M, C, w_out, b_out, w_ff1, b_ff1, w_ff2, b_ff2, w_po, b_po, eps=1e-5, lda=None, ldr1=None,
+             ldr2=None, ldo=None):
+    """Token-resident tail of a transformer block (csrc/rowchain.hip): out = proj_out(FF2(GEGLU(LN(h2))) + h2) + res2 with
+    h2 = to_out(a) + res1.  Weights / biases: pack_rowgemm forms (to_out plain; FF1 with the LayerNorm folded and geglu=True; FF2;
+    proj_out)."""
+    op = L2dOp()
+    op.kind = _lib.OP_ROWCHAIN
+    for t_, n_ in ((w_out, C * C), (w_ff1, 8 * C * C), (w_ff2, 4 * C * C), (w_po, C * C)):
+        assert t_.dtype == torch.float16 and t_.numel() == n_, (t_.shape, n_)
+    for t_, n_ in ((b_out, C), (b_ff1, 8 * C), (b_ff2, C), (b_po, C)):
+        assert t_.dtype == torch.float32 and t_.numel() == n_, (t_.shape, n_)
+    op.p[0], op.p[1], op.p[2], op.p[3] = _ptr(_h(a)), _ptr(_h(res1)), _ptr(_h(res2)), _ptr(_h(out))
+    op.p[4], op.p[5], op.p[6], op.p[7] = _ptr(_h(w_out)), _ptr(b_out), _ptr(_h(w_ff1)), _ptr(b_ff1)
+    op.p[8], op.p[11], op.p[12], op.p[13] = _ptr(_h(w_ff2)), _ptr(b_ff2), _ptr(_h(w_po)), _ptr(b_po)
+    op.i[0], op.i[1] = int(M), int(C)
+    op.i[2], op.i[3], op.i[4], op.i[5] = int(lda or C), int(ldr1 or C), int(ldr2 or C), int(ldo or C)
+    op.f[0] = float(eps)
+    return op, (a, res1, res2, out, w_out, b_out, w_ff1, b_ff1, w_ff2, b_ff2, w_po, b_po)
 
 
 def pconv_patch(B: int, H: int, W: int, Nout: int, C1: int, C2: int = 0):

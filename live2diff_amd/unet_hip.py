@@ -189,6 +189,7 @@ class HipStreamingUNet:
         RG_PLAIN_MAX_K = int(os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"))
         RG_FF1_MAX_K = int(os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))     # A/B knob: GEGLU GEMMs wider than this stay on igemm
         ws_lv = self.ws_levels
+        chain_on = os.environ.get("L2D_ROWCHAIN", "1") != "0"        # A/B knob: 0 = the four separate launches of a block's tail
 
         def rg_ok(wname):
             n, k = sd[wname].shape[0], sd[wname][0].numel()
@@ -245,6 +246,9 @@ class HipStreamingUNet:
             rg = rg_ok(pw) and sd[pw].shape[0] % 64 == 0 and sd[pw][0].numel() <= RG_FF1_MAX_K
             if rg:
                 W[name + ".rw1"], W[name + ".rb1"] = ops.pack_rowgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"), geglu=True)
+                if chain_on and sd[pw][0].numel() == ops.ROWCHAIN_C:
+                    # the token-resident block tail (rowchain.hip) streams FF2 in the row GEMM's fragment order too (K = 4 C)
+                    W[name + ".net.2.rw"], W[name + ".net.2.rb"] = ops.pack_rowgemm(g(name + ".net.2.weight"), g(name + ".net.2.bias"))
             if not rg or old:
                 W[name + ".w1"], W[name + ".b1"] = ops.pack_geglu(g(pw), g(pb))
             lin(name + ".net.2", old=old, lvl=lvl)
@@ -470,7 +474,7 @@ class HipStreamingUNet:
         return dict(ws_levels=[bool(v) for v in self.ws_levels],
                     old_levels=[((self.h >> l) * (self.w >> l)) % 32 != 0 for l in range(nl)],
                     ws_skip=sorted(ops._WS_SKIP), ws_large=sorted(ops._WS_LARGE), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
-                    rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
+                    rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rowchain=os.environ.get("L2D_ROWCHAIN", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
                     rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))
 
     @staticmethod
@@ -774,6 +778,19 @@ class HipStreamingUNet:
             free(hid)
             return out
 
+        def block_tail(ao: _Act, res1: _Act, res2: _Act, to_out, ff, proj_out) -> Optional[_Act]:
+            """attention output projection + residual -> LayerNorm -> GEGLU -> FF2 + residual -> proj_out + block residual as ONE
+            token-resident launch (rowchain.hip) where the level's M / 32 blocks fill the chip (C = 320); None = not here."""
+            T, C = ao.H * ao.W, ao.C
+            keys = (to_out + ".rw", to_out + ".rb", ff + ".rw1", ff + ".rb1", ff + ".net.2.rw", ff + ".net.2.rb", proj_out + ".rw", proj_out + ".rb")
+            if not (st.rg and ops.rowchain_ok(B * T, C, T) and all(k in W for k in keys)):
+                return None
+            out = new_act(C, ao.H, ao.W)
+            out.producer = add(ops.rowchain(ao.buf, res1.buf, res2.buf, out.buf, M=B * T, C=C, w_out=W[keys[0]], b_out=W[keys[1]],
+                                            w_ff1=W[keys[2]], b_ff1=W[keys[3]], w_ff2=W[keys[4]], b_ff2=W[keys[5]], w_po=W[keys[6]],
+                                            b_po=W[keys[7]], eps=1e-5))
+            return out
+
         def resnet(x: _Act, name, skip: Optional[_Act] = None) -> _Act:
             hn = gn(x, name + ".norm1", cfg.norm_eps, True, x2=skip)
             h1 = conv3(hn, name + ".conv1", rowbias=self.temb_offsets[name])
@@ -850,6 +867,10 @@ class HipStreamingUNet:
                                sk=(TEXT_PAD * self.text_total if Bt > 1 else 0),
                                svt=(self.text_total * TEXT_PAD if Bt > 1 else 0), so=T * C, k_off=off, vt_off=off * TEXT_PAD))
             free(q2)
+            tail = block_tail(ao, y2, x, b + ".attn2.to_out.0", b + ".ff", name + ".proj_out")
+            if tail is not None:
+                free(ao); free(y2)
+                return tail
             y3 = lin(ao, b + ".attn2.to_out.0", res=y2)
             free(ao); free(y2)
             if (st.ws and (b + ".ff.ww1") in W) or (st.rg and T % 32 == 0 and (b + ".ff.rw1") in W):
@@ -891,6 +912,11 @@ class HipStreamingUNet:
                                               F=B, T=T, C=C, L=L, H=cfg.temporal_heads))
                 st.tattn_ops.append((op.tag, idx))
                 ar.release(qkv)
+                if j == 1:
+                    tail = block_tail(ao, y, x, a + ".to_out.0", b + ".ff", t + ".proj_out")
+                    if tail is not None:
+                        free(ao); free(y)
+                        return tail
                 y2 = linear(ao, a + ".to_out.0", res=y)
                 free(ao); free(y)
                 y = y2

@@ -97,7 +97,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib.l2d_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.l2d_abi_version() == _lib.ABI_VERSION == 5
     assert ctypes.sizeof(_lib.L2dOp) == 312          # ABI v4: 16 pointers + 32 ints + 4 int64 + 4 floats (+ kind, tag)
     # error path without a device: refused loudly, no fallback
     ops = (_lib.L2dOp * 1)()
@@ -311,10 +311,13 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     # 380 GEMM launches in round 2; the 16 V^T projections now ride in the q | k | V^T row GEMMs
     # (21 level-0 / level-1 3x3 convs: patch kernel; the levels with <= 512 stream tokens: weight-streaming GEMM where the in-frame
     #  tuner found it faster, round 4)
-    gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV, _lib.OP_WSGEMM) if k_ in tot]
+    gemm = [tot[k_] for k_ in (_lib.OP_IGEMM, _lib.OP_ROWGEMM, _lib.OP_PCONV, _lib.OP_WSGEMM, _lib.OP_ROWCHAIN) if k_ in tot]
+    # (round 5, rowchain.hip: the tail of each of the 10 level-0 transformer blocks -- to_out + residual, LayerNorm + GEGLU, FF2 +
+    #  residual, proj_out + residual -- is ONE token-resident launch instead of four)
+    assert tot[_lib.OP_ROWCHAIN][0] == 10
     # (round 5: the level-1 3x3 convs whose contraction is long -- 9 of the 10 -- and the level-1 q | k | V^T / GEGLU layers moved to the
     #  weight-streaming kernel too, per measured shape: the `large` list of wsgemm_tuned.json)
-    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 and tot[_lib.OP_PCONV][0] == 12
+    assert tot[_lib.OP_FLASH_ATTN][0] == 32 and sum(g_[0] for g_ in gemm) == 380 - 16 - 30 and tot[_lib.OP_PCONV][0] == 12
     assert tot.get(_lib.OP_WSGEMM, [0])[0] >= 100
     assert abs(sum(g_[1] for g_ in gemm) / 1.9723e12 - 1) < 1e-3          # the figure quoted in DESIGN.md section 3
     assert _lib.OP_LAYERNORM not in tot
