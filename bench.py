@@ -59,7 +59,11 @@ def op_work(op, kinds):
         taps, C, M, Nout = i[0], i[1] + i[2], i[13], i[14]
         return 2.0 * M * Nout * taps * C, 2.0 * (M * C + Nout * taps * C + M * (Nout // 2 if i[19] == 1 else Nout))
     if k == kinds.OP_ROWCHAIN:
-        M, C = i[0], i[1]                 # to_out C x C, GEGLU C x 8C, FF2 4C x C, proj_out C x C; in: a, res1, res2; out
+        M, C = i[0], i[1]
+        if i[6] == 1:                     # head segment: A (C x C) + B (passes x C x C); in: x (+ resA); out: h, passes x C columns
+            nb = i[7]
+            return 2.0 * M * (1 + nb) * C * C, 2.0 * (M * C * (2 + nb + (1 if op.p[1] else 0)) + (1 + nb) * C * C)
+        # tail: to_out C x C, GEGLU C x 8C, FF2 4C x C, proj_out C x C; in: a, res1, res2; out
         return 2.0 * M * 14 * C * C, 2.0 * (4 * M * C + 14 * C * C)
     if k == kinds.OP_FLASH_ATTN:
         B, H, d, Tq, Tk = i[0], i[1], i[2], i[3], i[4]
@@ -154,7 +158,7 @@ def op_dims(op, kinds):
     if op.kind == kinds.OP_WSGEMM:
         return f"taps{i[0]} M{i[13]} N{i[14]} K{i[0] * (i[1] + i[2])} e{i[19]} p{i[20]} w{i[9]} t{i[10]} l{i[11]} S{max(1, i[12])} tr{i[21]} nt{i[23]}"
     if op.kind == kinds.OP_ROWCHAIN:
-        return f"M{i[0]} C{i[1]}"
+        return f"M{i[0]} C{i[1]} " + (f"head p{i[7]} tr{i[8]} gn{int(bool(op.p[14]))} res{int(bool(op.p[1]))}" if i[6] == 1 else "tail")
     if op.kind == kinds.OP_FLASH_ATTN:
         return f"B{i[0]} H{i[1]} d{i[2]} Tq{i[3]} Tk{i[4]}"
     if op.kind in (kinds.OP_TATTN_STREAM, kinds.OP_TATTN_WARMUP):

@@ -290,6 +290,241 @@ __global__ __launch_bounds__(C) void rowchain_tail_kernel(RowChainArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Head segments of a transformer block, the same machinery: TWO dependent layers in one launch --
+//     h   = A( norm?(x) ) + bA (+ resA)      A = proj_in behind the block's GroupNorm (statistics from x's producers: the prologue of
+//                                            rowgemm.hip) or an attention's to_out with its residual      -> stored (the residual stream)
+//     out = B( LayerNorm(h) ) + bB           B = q | k | v of the next attention (NBP passes of C packed rows; TRL: the LAST pass leaves
+//                                            transposed, V^T[sample][channel][token] for the flash kernel) or the cross-attention's to_q
+// (reference: attention.py:102-110,221-250; motion_module.py:273-279,401-427).  Replaces two row-GEMM launches and the round trip of h.
+struct RowHeadArgs {
+    const h16 *x, *resA;
+    h16 *hout, *out, *outT;
+    const h16 *wA, *wB;
+    const float *bA, *bB;              // bB may be null (q | k | v carry no bias)
+    const long long *gnacc;            // GroupNorm prologue: [samples][G][2] fixed-point statistics of x, or null
+    long long sT;
+    int M, ldx, ldrA, ldh, ldo, ldt, T, G;
+    float eps_gn, eps_ln;
+};
+
+template <int C, int NBP, bool TRL>
+__global__ __launch_bounds__(C) void rowchain_head_kernel(RowHeadArgs a) {
+    constexpr int BM = RC_BM, NW = C / 64, NT = 2, SK = C / 16, RD = 8, NTHR = NW * 64;
+    constexpr int SLOTS = C / 8, RSTEP = NTHR / SLOTS, LPT = BM / RSTEP, NS8 = SLOTS / 8;
+    static_assert(C % 64 == 0 && NTHR % SLOTS == 0 && BM % RSTEP == 0 && NTHR == C && SK >= RD, "geometry");
+    extern __shared__ __attribute__((aligned(16))) h16 smem[];                  // the ONLY LDS object
+    h16 *X = smem, *Hh = smem + BM * C, *S0 = smem + 2 * BM * C;                // S0 | S1: staging of B's output tiles (S1: + padding for V^T)
+    constexpr int STG = C * (BM + 8) > BM * C ? C * (BM + 8) : BM * C;          // halfs per staging tile (channel-major V^T rows are BM + 8 wide)
+    h16 *S1 = S0 + STG;
+    float *bl = reinterpret_cast<float *>(S1 + STG);                            // bA [C] | bB [NBP C] | GroupNorm: sc [C] | sh [C] | rstd [32] | shift [32]
+    float *blA = bl, *blB = bl + C, *tab = bl + C + NBP * C;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int wlane = lane * 8;
+    int xoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xoff[u] = (((2 * u + lh) * BM) + (l32 ^ (4 * u + 2 * lh))) * 8;
+    const int slot = tid % SLOTS, r0 = tid / SLOTS;
+    const bool gnp = a.gnacc != nullptr, resa = a.resA != nullptr;
+
+    h16x8 wr[RD][NT];
+    {
+        h16x8 va[LPT], vr[LPT];
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const long long row = m0 + r0 + RSTEP * i;
+            va[i] = l2d_ld8(a.x + row * a.ldx + slot * 8);
+            vr[i] = resa ? l2d_ld8(a.resA + row * a.ldrA + slot * 8) : l2d_zero8();
+        }
+        const float vbA = a.bA[tid];
+        float vbB[NBP];
+#pragma unroll
+        for (int k = 0; k < NBP; ++k) vbB[k] = a.bB ? a.bB[tid + C * k] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        rc_ring_request<SK, RD, NT>(wr, a.wA + (long long)(wave * NT) * SK * 512, wlane);
+        blA[tid] = vbA;
+#pragma unroll
+        for (int k = 0; k < NBP; ++k) blB[tid + C * k] = vbB[k];
+        if (gnp) {
+            // (rstd, -mean rstd) per channel of this block's sample, exactly as rowgemm.hip's prologue 2 (gamma / beta live in wA / bA)
+            float *rstd_s = tab + 2 * C, *shf_s = rstd_s + 32;
+            if (tid < a.G) {
+                const long long *src = a.gnacc + ((long long)(m0 / a.T) * a.G + tid) * 2;
+                const float s1 = (float)((double)src[0] * (1.0 / 1048576.0));
+                const float q1 = (float)((double)src[1] * (1.0 / 4096.0));
+                const float inv = 1.0f / ((float)a.T * (float)(C / a.G));
+                const float mean = s1 * inv;
+                const float var = fmaxf(q1 * inv - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + a.eps_gn);
+                rstd_s[tid] = rstd;
+                shf_s[tid] = -mean * rstd;
+            }
+            __syncthreads();
+            const int g = (int)(((float)tid + 0.5f) * ((float)a.G / (float)C));
+            tab[tid] = rstd_s[g];
+            tab[C + tid] = shf_s[g];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = r0 + RSTEP * i;
+            const int dst = ((slot * BM) + (row ^ (2 * (slot & 7)))) * 8;
+            h16x8 v = va[i];
+            if (gnp) {
+                const int c0 = slot * 8;
+                const f32x4 sa = *reinterpret_cast<const f32x4 *>(tab + c0), sb = *reinterpret_cast<const f32x4 *>(tab + c0 + 4);
+                const f32x4 ha = *reinterpret_cast<const f32x4 *>(tab + C + c0), hb = *reinterpret_cast<const f32x4 *>(tab + C + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (h16)((float)va[i][e] * sa[e] + ha[e]);
+                    v[4 + e] = (h16)((float)va[i][4 + e] * sb[e] + hb[e]);
+                }
+            }
+            l2d_st8(X + dst, v);
+            l2d_st8(Hh + dst, vr[i]);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+    // ---- layer A: h = A(x) + bA (+ resA) -> H
+    rc_kloop<SK, RD, NT>(acc, wr, a.wA + (long long)(wave * NT) * SK * 512, wlane, X, xoff);
+    rc_ring_request<SK, RD, NT>(wr, a.wB + (long long)(wave * NT) * SK * 512, wlane);           // B, pass 0
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int c = (wave * NT + i) * 32 + 8 * g4 + 4 * lh;
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(blA + c);
+            h16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[i][4 * g4 + e] + bb[e]);
+            h16x4 *hp = reinterpret_cast<h16x4 *>(Hh + rc_addr(c, l32));
+            *hp = resa ? o + *hp : o;
+        }
+    __syncthreads();
+    // ---- h -> HBM (whole rows: the 8 lanes of a row store 128 contiguous bytes per step) and LayerNorm(h) -> X
+    if (tid < BM * 8) {
+        const int r = tid >> 3, j = tid & 7;
+        h16x8 v[NS8];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS8; ++i) {
+            v[i] = l2d_ld8(Hh + (((j + 8 * i) * BM) + (r ^ (2 * j))) * 8);
+            l2d_st8(a.hout + (long long)(m0 + r) * a.ldh + (j + 8 * i) * 8, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += (float)v[i][e];
+        }
+        const float mean = rc_row_sum8(t) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS8; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; q += d * d; }
+        const float rstd = rsqrtf(rc_row_sum8(q) / (float)C + a.eps_ln);
+#pragma unroll
+        for (int i = 0; i < NS8; ++i) {
+            h16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)(((float)v[i][e] - mean) * rstd);
+            l2d_st8(X + (((j + 8 * i) * BM) + (r ^ (2 * j))) * 8, o);
+        }
+    }
+    __syncthreads();
+    // ---- layer B: NBP passes of C packed rows; every pass stages its tile (double-buffered) and leaves as whole rows / V^T rows
+#pragma unroll
+    for (int p = 0; p < NBP; ++p) {
+        const int t0 = p * NW * NT + wave * NT;
+        rc_kloop<SK, RD, NT>(acc, wr, a.wB + (long long)t0 * SK * 512, wlane, X, xoff);
+        if (p + 1 < NBP) rc_ring_request<SK, RD, NT>(wr, a.wB + (long long)(t0 + NW * NT) * SK * 512, wlane);
+        h16 *St = (p & 1) ? S1 : S0;
+        constexpr int PT = BM + 8;
+        const bool tr = TRL && p == NBP - 1;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = (wave * NT + i) * 32 + 8 * g4 + 4 * lh;
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(blB + p * C + c);
+                if (tr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) St[(c + e) * PT + l32] = (h16)(acc[i][4 * g4 + e] + bb[e]);      // channel-major
+                } else {
+                    h16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[i][4 * g4 + e] + bb[e]);
+                    *reinterpret_cast<h16x4 *>(St + rc_addr(c, l32)) = o;
+                }
+            }
+        __syncthreads();
+        if (tr) {
+            // V^T[sample][channel][token]: 16-byte pieces of 8 tokens (T % 32 == 0: the block lies in one sample)
+            const int b = m0 / a.T, tb = m0 - b * a.T;
+            h16 *ob = a.outT + (long long)b * a.sT + tb;
+            constexpr int CPT = BM / 8;
+            for (int idx = tid; idx < C * CPT; idx += NTHR) {
+                const int ch = idx / CPT, cq = idx - ch * CPT;
+                l2d_st8(ob + (long long)ch * a.ldt + cq * 8, l2d_ld8(St + ch * PT + cq * 8));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const int row = r0 + RSTEP * i;
+                l2d_st8(a.out + (long long)(m0 + row) * a.ldo + p * C + slot * 8, l2d_ld8(St + ((slot * BM) + (row ^ (2 * (slot & 7)))) * 8));
+            }
+        }
+    }
+}
+
+template <int C, int NBP, bool TRL>
+static void launch_rh(const RowHeadArgs &a, hipStream_t s) {
+    constexpr size_t STG = (size_t)(C * (RC_BM + 8) > RC_BM * C ? C * (RC_BM + 8) : RC_BM * C);
+    constexpr size_t LDS = (size_t)(2 * RC_BM * C + 2 * STG) * 2 + (size_t)(C + NBP * C + 2 * C + 64) * 4;
+    static_assert(LDS <= 163840, "tiles do not fit the CU's LDS");
+    static bool attr_done_dev[L2D_MAX_DEV] = {false};
+    bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
+    if (LDS > 65536 && !attr_done) {
+        if (hipFuncSetAttribute((const void *)rowchain_head_kernel<C, NBP, TRL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
+        else (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL((rowchain_head_kernel<C, NBP, TRL>), dim3(a.M / RC_BM), dim3(C), LDS, s, a);
+}
+
+static int l2d_launch_rowchain_head(const l2d_op *op, hipStream_t s) {
+    RowHeadArgs a;
+    a.x = (const h16 *)op->p[0]; a.resA = (const h16 *)op->p[1]; a.hout = (h16 *)op->p[2]; a.out = (h16 *)op->p[3];
+    a.wA = (const h16 *)op->p[4]; a.bA = (const float *)op->p[5]; a.wB = (const h16 *)op->p[6]; a.bB = (const float *)op->p[7];
+    a.outT = (h16 *)op->p[8]; a.gnacc = (const long long *)op->p[14];
+    a.M = op->i[0];
+    const int C = op->i[1];
+    a.ldx = op->i[2]; a.ldrA = op->i[3]; a.ldh = op->i[4]; a.ldo = op->i[5];
+    const int nbp = op->i[7], trl = op->i[8];
+    a.ldt = op->i[9]; a.T = op->i[10]; a.G = op->i[11];
+    a.sT = op->l[0];
+    a.eps_ln = op->f[0]; a.eps_gn = op->f[1];
+    unsigned long long ptrs = (unsigned long long)a.x | (unsigned long long)a.resA | (unsigned long long)a.hout | (unsigned long long)a.out |
+                              (unsigned long long)a.wA | (unsigned long long)a.wB | (unsigned long long)a.outT | (unsigned long long)a.bA | (unsigned long long)a.bB;
+    const bool geo = (nbp == 1 && !trl) || (nbp == 3);
+    if (!a.x || !a.hout || !a.wA || !a.bA || !a.wB || C != 320 || a.M <= 0 || (a.M % RC_BM) || !geo || a.ldx < C || a.ldh < C ||
+        ((a.ldx | a.ldh) % 8) || (a.resA && (a.ldrA < C || (a.ldrA % 8))) || (ptrs & 15) || !(a.eps_ln > 0.f) ||
+        (nbp - (trl ? 1 : 0) > 0 && (!a.out || a.ldo < (nbp - (trl ? 1 : 0)) * C || (a.ldo % 8))) ||
+        (trl && (!a.outT || a.T <= 0 || (a.T % RC_BM) || (a.M % a.T) || (a.ldt % 8) || a.ldt < a.T)) ||
+        (a.gnacc && (a.T <= 0 || (a.T % RC_BM) || (a.M % a.T) || a.G <= 0 || a.G > 32 || (C % a.G) || !(a.eps_gn > 0.f)))) {
+        l2d_set_error("rowchain head(tag %d): invalid arguments (M=%d C=%d passes=%d transposed=%d ldx=%d ldh=%d ldo=%d T=%d G=%d)", op->tag, a.M,
+                      C, nbp, trl, a.ldx, a.ldh, a.ldo, a.T, a.G);
+        return L2D_EINVAL;
+    }
+    L2D_DRY_RETURN();
+    if (nbp == 1) launch_rh<320, 1, false>(a, s);
+    else if (trl) launch_rh<320, 3, true>(a, s);
+    else launch_rh<320, 3, false>(a, s);
+    return l2d_check_launch("rowchain head", op->tag);
+}
+
 template <int C>
 static void launch_rc(const RowChainArgs &a, hipStream_t s) {
     constexpr size_t LDS = (size_t)(2 * RC_BM * C + RC_BM * 4 * C) * 2 + (size_t)(3 * C + 8 * C) * 4;
@@ -304,6 +539,7 @@ static void launch_rc(const RowChainArgs &a, hipStream_t s) {
 }
 
 int l2d_launch_rowchain(const l2d_op *op, hipStream_t s) {
+    if (op->i[6] == 1) return l2d_launch_rowchain_head(op, s);       // i6: 0 = block tail, 1 = head segment (two layers)
     RowChainArgs a;
     a.a = (const h16 *)op->p[0]; a.res1 = (const h16 *)op->p[1]; a.res2 = (const h16 *)op->p[2]; a.out = (h16 *)op->p[3];
     a.w0 = (const h16 *)op->p[4]; a.b0 = (const float *)op->p[5]; a.w1 = (const h16 *)op->p[6]; a.b1 = (const float *)op->p[7];

@@ -208,7 +208,7 @@ def gn_target(op, acc_ptr: int, **kw) -> bool:
 def rowchain_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
     """The same request to a rowchain op (its row phase accumulates like the row GEMM's; a block is 32 tokens of one sample)."""
     assert op.kind == _lib.OP_ROWCHAIN
-    if T % 32 or op.i[0] % T or G > 32 or (cpg | choff) & 1:
+    if op.i[6] != 0 or T % 32 or op.i[0] % T or G > 32 or (cpg | choff) & 1:          # (head segments feed attention, never a GroupNorm)
         return False
     if op.p[9] and (op.i[24], op.i[25]) != (T, G):
         return False
@@ -219,6 +219,31 @@ def rowchain_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int
     op.i[24], op.i[25] = int(T), int(G)
     op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
     return True
+
+
+def rowchain_head(x, hout, out, *, M, C, wA, bA, wB, bB=None, passes=1, resA=None, gn_acc_ptr=None, T=0, G=0, eps_gn=1e-6, eps_ln=1e-5,
+                  out_t=None, ldt=0, st=0, ldx=None, ldrA=None, ldh=None, ldo=None):
+    """Head segment of a transformer block (csrc/rowchain.hip, two dependent layers in one launch):
+    h = A(norm?(x)) + bA (+ resA) -> hout;  out = B(LayerNorm(h)) + bB, `passes` x C packed rows; with `out_t` the LAST pass is stored
+    transposed (V^T[sample][channel][ldt]) and `out` receives the first passes - 1.  gn_acc_ptr: GroupNorm prologue on x (statistics
+    [samples][G][2] from x's producers, T tokens per sample).  Weights: pack_rowgemm forms (norm affine folded)."""
+    op = L2dOp()
+    op.kind = _lib.OP_ROWCHAIN
+    assert wA.dtype == torch.float16 and wA.numel() == C * C and wB.dtype == torch.float16 and wB.numel() == passes * C * C
+    assert bA.dtype == torch.float32 and bA.numel() == C and (bB is None or (bB.dtype == torch.float32 and bB.numel() == passes * C))
+    trl = out_t is not None
+    ncol = (passes - (1 if trl else 0)) * C
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x)), (_ptr(_h(resA)) if resA is not None else None), _ptr(_h(hout))
+    op.p[3] = _ptr(_h(out)) if out is not None else None
+    op.p[4], op.p[5], op.p[6], op.p[7] = _ptr(_h(wA)), _ptr(bA), _ptr(_h(wB)), _ptr(bB)
+    op.p[8] = _ptr(_h(out_t)) if trl else None
+    op.p[14] = int(gn_acc_ptr) if gn_acc_ptr is not None else None
+    op.i[0], op.i[1] = int(M), int(C)
+    op.i[2], op.i[3], op.i[4], op.i[5] = int(ldx or C), int(ldrA or C), int(ldh or C), int(ldo or max(ncol, C))
+    op.i[6], op.i[7], op.i[8], op.i[9], op.i[10], op.i[11] = 1, int(passes), int(trl), int(ldt), int(T), int(G)
+    op.l[0] = int(st)
+    op.f[0], op.f[1] = float(eps_ln), float(eps_gn)
+    return op, (x, resA, hout, out, out_t, wA, bA, wB, bB)
 
 
 ROWCHAIN_C = 320                # the width the chain kernel is instantiated for (SD-1.5 level 0)

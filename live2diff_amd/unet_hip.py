@@ -503,7 +503,8 @@ class HipStreamingUNet:
         # They run when the conditioning changes (first frame, update_prompt, a new warm-up row), not every frame.
         cond_pl = _lib.OpList()
         st = SimpleNamespace(mode=mode, B=B, Bt=Bt, pl=pl, cond_pl=cond_pl, cond_key=None, arena=ar, tattn_ops=[], warm=False,
-                             ident={}, rg=os.environ.get("L2D_ROWGEMM", "1") != "0", ws=any(self.ws_levels))
+                             ident={}, rg=os.environ.get("L2D_ROWGEMM", "1") != "0", ws=any(self.ws_levels),
+                             chain_heads=os.environ.get("L2D_ROWCHAIN_HEADS", "1") != "0")
         cur = [cond_pl]
 
         def add(opk):
@@ -791,6 +792,26 @@ class HipStreamingUNet:
                                             b_po=W[keys[7]], eps=1e-5))
             return out
 
+        def block_head(x: _Act, a_name, b_name, outbuf, passes, *, res: Optional[_Act] = None, gn_of: Optional[_Act] = None, out_t=None,
+                       ldt=0, stt=0, ldo=None) -> Optional[_Act]:
+            """Two dependent layers as one token-resident launch (rowchain.hip head segment): h = A(x) (+ res) -- or A(GroupNorm(x)) with
+            the statistics from x's producers -- stored as the residual stream, then B(LayerNorm(h)) -> outbuf (q | k | v, q | k + V^T,
+            or the cross-attention's query).  Returns h, or None when the segment does not run here (the caller emits the two launches)."""
+            T, C = x.H * x.W, x.C
+            keys = (a_name + ".rw", a_name + ".rb", b_name + ".rw")
+            if not (st.rg and st.chain_heads and ops.rowchain_ok(B * T, C, T) and all(k in W for k in keys)):
+                return None
+            acc_ptr = None
+            if gn_of is not None:
+                acc_ptr = gn_stats_target(gn_of, None, T, C // G)
+                if acc_ptr is None:
+                    return None
+            h = new_act(C, x.H, x.W)
+            add(ops.rowchain_head(x.buf, h.buf, outbuf, M=B * T, C=C, wA=W[keys[0]], bA=W[keys[1]], wB=W[keys[2]], bB=W.get(b_name + ".rb"),
+                                  passes=passes, resA=(res.buf if res is not None else None), gn_acc_ptr=acc_ptr, T=T, G=G,
+                                  eps_gn=cfg.transformer_norm_eps, eps_ln=1e-5, out_t=out_t, ldt=ldt, st=stt, ldo=ldo))
+            return h
+
         def resnet(x: _Act, name, skip: Optional[_Act] = None) -> _Act:
             hn = gn(x, name + ".norm1", cfg.norm_eps, True, x2=skip)
             h1 = conv3(hn, name + ".conv1", rowbias=self.temb_offsets[name])
@@ -817,7 +838,18 @@ class HipStreamingUNet:
             # every linear layer picks its kernel by the packed form it finds: weight-streaming (.ww, few-token levels), token-row
             # (.rw) or implicit GEMM (.w)
             lin = lambda a_, nm, **k_: linear(a_, nm, **k_) if (use_ws(nm) or use_rg(nm)) else linear(a_, nm, wkey=nm + ".w", **k_)
-            if rg_in:
+            y = None
+            qk = vt = None
+            if rg_in and rg and T % 32 == 0:
+                # proj_in behind the block's GroupNorm + norm1 -> q | k | V^T as one launch (head segment of rowchain.hip)
+                qk, vt = ar.alloc(B * T * 2 * C), ar.alloc(B * C * ldvt)
+                y = block_head(x, name + ".proj_in", b + ".attn1.qkv", qk, 3, gn_of=x, out_t=vt, ldt=ldvt, stt=C * ldvt, ldo=2 * C)
+                if y is None:
+                    ar.release(qk); ar.release(vt)
+                    qk = vt = None
+            if y is not None:
+                pass
+            elif rg_in:
                 y = gn_linear(x, name + ".norm", cfg.transformer_norm_eps, name + ".proj_in")
             else:
                 if (name + ".proj_in.w") not in W:
@@ -828,9 +860,13 @@ class HipStreamingUNet:
                 y = linear(hn, name + ".proj_in", wkey=name + ".proj_in.w")
                 free(hn)
             # --- self attention: norm1 -> q | k | V^T
-            qk = ar.alloc(B * T * 2 * C)
-            vt = ar.alloc(B * C * ldvt)
-            if use_ws(b + ".attn1.qkv"):
+            fused_qkv = qk is not None
+            if not fused_qkv:
+                qk = ar.alloc(B * T * 2 * C)
+                vt = ar.alloc(B * C * ldvt)
+            if fused_qkv:
+                pass
+            elif use_ws(b + ".attn1.qkv"):
                 wslin(y.buf, B * T, C, b + ".attn1.qkv.ww", qk, 2 * C, T=T, bias=W.get(b + ".attn1.qkv.wb"), colsum=W[b + ".attn1.qkv.wcs"], pro=1,
                       out_t=vt, ntr=C, ldt=ldvt, stt=C * ldvt)
             elif rg:
@@ -847,11 +883,17 @@ class HipStreamingUNet:
             add(ops.flash_attn(qk, qk, vt, ao.buf, B=B, H=cfg.num_heads, d=d, Tq=T, Tk=T, ldq=2 * C, ldk=2 * C, ldvt=ldvt,
                                ldo=C, sq=T * 2 * C, sk=T * 2 * C, svt=C * ldvt, so=T * C, k_off=C))
             ar.release(qk); ar.release(vt)
-            y2 = lin(ao, b + ".attn1.to_out.0", res=y)
+            # --- attn1.to_out + residual -> norm2 -> cross-attention query: one launch where the head segment runs
+            q2 = new_act(C, x.H, x.W)
+            y2 = block_head(ao, b + ".attn1.to_out.0", b + ".attn2.to_q", q2.buf, 1, res=y)
+            fused_q = y2 is not None
+            if not fused_q:
+                y2 = lin(ao, b + ".attn1.to_out.0", res=y)
             free(ao); free(y)
             # --- text cross attention (K / V^T of all 16 layers come from two batched GEMMs at plan start)
-            q2 = new_act(C, x.H, x.W)
-            if use_ws(b + ".attn2.to_q"):
+            if fused_q:
+                pass
+            elif use_ws(b + ".attn2.to_q"):
                 wslin(y2.buf, B * T, C, b + ".attn2.to_q.ww", q2.buf, C, T=T, bias=W.get(b + ".attn2.to_q.wb"), colsum=W[b + ".attn2.to_q.wcs"], pro=1)
             elif use_rg(b + ".attn2.to_q") and T % 32 == 0:
                 ln_rowlin(y2, b + ".attn2.to_q", q2.buf, C)
@@ -887,12 +929,20 @@ class HipStreamingUNet:
         def motion(x: _Act, name, idx_base: int) -> _Act:
             T, C = x.H * x.W, x.C
             t = name + ".temporal_transformer"
-            y = gn_linear(x, t + ".norm", cfg.transformer_norm_eps, t + ".proj_in")
             b = t + ".transformer_blocks.0"
+            # proj_in behind the module's GroupNorm + LayerNorm -> q | k | v of the first attention as one launch where the head segment runs
+            qkv_next = ar.alloc(B * T * 3 * C)
+            y = block_head(x, t + ".proj_in", b + ".attention_blocks.0.qkv", qkv_next, 3, gn_of=x)
+            if y is None:
+                ar.release(qkv_next)
+                qkv_next = None
+                y = gn_linear(x, t + ".norm", cfg.transformer_norm_eps, t + ".proj_in")
             for j in range(2):
                 a = b + f".attention_blocks.{j}"
-                qkv = ar.alloc(B * T * 3 * C)
-                if use_ws(a + ".qkv"):
+                qkv = qkv_next if qkv_next is not None else ar.alloc(B * T * 3 * C)
+                if qkv_next is not None:
+                    qkv_next = None
+                elif use_ws(a + ".qkv"):
                     wslin(y.buf, B * T, C, a + ".qkv.ww", qkv, 3 * C, T=T, bias=W.get(a + ".qkv.wb"), colsum=W[a + ".qkv.wcs"], pro=1)
                 elif use_rg(a + ".qkv"):
                     ln_rowlin(y, a + ".qkv", qkv, 3 * C)
@@ -917,7 +967,16 @@ class HipStreamingUNet:
                     if tail is not None:
                         free(ao); free(y)
                         return tail
-                y2 = linear(ao, a + ".to_out.0", res=y)
+                y2 = None
+                if j == 0:
+                    # to_out + residual -> LayerNorm -> q | k | v of the second attention
+                    qkv_next = ar.alloc(B * T * 3 * C)
+                    y2 = block_head(ao, a + ".to_out.0", b + ".attention_blocks.1.qkv", qkv_next, 3, res=y)
+                    if y2 is None:
+                        ar.release(qkv_next)
+                        qkv_next = None
+                if y2 is None:
+                    y2 = linear(ao, a + ".to_out.0", res=y)
                 free(ao); free(y)
                 y = y2
             if (st.ws and (b + ".ff.ww1") in W) or use_rg(b + ".ff") or (st.rg and (b + ".ff.rw1") in W):

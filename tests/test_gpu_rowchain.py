@@ -132,3 +132,73 @@ def test_rowchain_strided_operands_and_rejects(L, layers):
     op.i[1] = 640
     with pytest.raises(_lib.L2DError):
         L.run((op, keep))                                                                      # C = 320 only
+
+
+# ----------------------------------------------------------------------------------------------- head segments (two layers per launch)
+@pytest.mark.parametrize("kind", ["gn_qkv", "res_qkv", "gn_qkvT", "res_q"])
+def test_rowchain_head_segments(L, kind):
+    """h = A(norm?(x)) + bA (+ res) -> stored; out = B(LayerNorm(h)) (+ bB): the four shapes of the plan -- proj_in behind the block's
+    GroupNorm + q | k | v (motion) / q | k + V^T (spatial), to_out + residual + q | k | v (motion) / + the cross-attention query
+    (spatial) -- against fp32 torch and against the two row-GEMM launches each one replaces (the same rounding points)."""
+    from live2diff_amd import _lib
+    B, T, G = 2, 4096, 32
+    M = B * T
+    gnp, passes, trl = kind.startswith("gn"), (1 if kind == "res_q" else 3), kind == "gn_qkvT"
+    x0, res = rnd(M, C, seed=31), rnd(M, C, seed=32)
+    wa, ba = rnd(C, C, seed=33, scale=C ** -0.5), rnd(C, seed=34, scale=0.1).float()
+    ga, bta = (1 + 0.2 * rnd(C, seed=35).float()).half(), (0.2 * rnd(C, seed=36).float()).half()      # the GroupNorm's affine (folded into A)
+    wb = rnd(passes * C, C, seed=37, scale=C ** -0.5)
+    gl, btl = (1 + 0.2 * rnd(C, seed=38).float()).half(), (0.2 * rnd(C, seed=39).float()).half()      # the LayerNorm's affine (folded into B)
+    f = lambda t: t.float()
+    # x arrives through an identity igemm that accumulates its GroupNorm statistics (as every producer in the plan does)
+    x = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    acc = torch.zeros(B, G, 2, dtype=torch.int64, device=DEV)
+    wi = L.pack_linear(torch.eye(C).half().to(DEV))
+    op, keep = L.igemm(x0.to(DEV), wi, x, M=M, Nout=C, C1=C, ldx1=C, CinP=wi.shape[1], ldo=C, tile=2, variant=1)
+    assert L.gn_target(op, acc.data_ptr(), T=T, G=G, cpg=C // G, choff=0)
+    L.run((op, keep + (acc,)))
+    if gnp:
+        xn = F.group_norm(f(x0).view(B, T, C).permute(0, 2, 1), G, f(ga), f(bta), 1e-6).permute(0, 2, 1).reshape(M, C)
+        h = (xn @ f(wa).t() + ba).half().float()
+        wpa, bpa = L.pack_rowgemm(wa.to(DEV), ba.to(DEV), ga.to(DEV), bta.to(DEV))
+    else:
+        h = ((f(x0) @ f(wa).t() + ba).half().float() + f(res)).half().float()
+        wpa, bpa = L.pack_rowgemm(wa.to(DEV), ba.to(DEV))
+    ref = F.layer_norm(h, (C,), f(gl), f(btl), 1e-5) @ f(wb).t()
+    wpb, bpb = L.pack_rowgemm(wb.to(DEV), None, gl.to(DEV), btl.to(DEV))
+    ldvt = T
+    hout = torch.zeros(M, C, dtype=torch.float16, device=DEV)
+    ncol = (passes - (1 if trl else 0)) * C
+    out = torch.zeros(M, ncol, dtype=torch.float16, device=DEV)
+    vt = torch.zeros(B, C, ldvt, dtype=torch.float16, device=DEV) if trl else None
+    kw = dict(M=M, C=C, wA=wpa, bA=bpa, wB=wpb, bB=bpb, passes=passes, T=T, G=G, eps_gn=1e-6, eps_ln=1e-5, ldo=ncol)
+    if gnp:
+        kw.update(gn_acc_ptr=acc.data_ptr())
+    else:
+        kw.update(resA=res.to(DEV))
+    if trl:
+        kw.update(out_t=vt, ldt=ldvt, st=C * ldvt)
+    pl = _lib.OpList(); pl.append(*L.rowchain_head(x, hout, out, **kw))
+    pl.run(); torch.cuda.synchronize()
+    eh, eo = relerr(hout, h), relerr(out, ref[:, :ncol])
+    assert eh <= 2e-3 and eo <= 3e-3, (kind, eh, eo)
+    if trl:
+        ev = relerr(vt.permute(0, 2, 1).reshape(M, C), ref[:, 2 * C:])
+        assert ev <= 3e-3, (kind, ev)
+    # the two launches it replaces
+    h2 = torch.zeros(M, C, dtype=torch.float16, device=DEV)
+    o2 = torch.zeros(M, ncol, dtype=torch.float16, device=DEV)
+    vt2 = torch.zeros(B, C, ldvt, dtype=torch.float16, device=DEV) if trl else None
+    un = _lib.OpList()
+    if gnp:
+        un.append(*L.rowgemm(x, wpa, h2, M=M, K=C, Nout=C, ldx=C, ldo=C, bias=bpa, pro=2, eps=1e-6, T=T, G=G, gn_acc_ptr=acc.data_ptr()))
+    else:
+        un.append(*L.rowgemm(x, wpa, h2, M=M, K=C, Nout=C, ldx=C, ldo=C, bias=bpa, res=res.to(DEV), ldr=C))
+    un.append(*L.rowgemm(h2, wpb, o2, M=M, K=C, Nout=passes * C, ldx=C, ldo=ncol, bias=bpb, pro=1, eps=1e-5, T=T,
+                         **(dict(out_t=vt2, ntr=C, ldt=ldvt, st=C * ldvt) if trl else {})))
+    un.run(); torch.cuda.synchronize()
+    assert relerr(hout, h2) <= 1e-3 and relerr(out, o2) <= 1.5e-3, (kind, relerr(hout, h2), relerr(out, o2))
+    if trl:
+        assert relerr(vt, vt2) <= 1.5e-3
+    t_c, t_u = pl.time_ms(20), un.time_ms(20)
+    print(f"{kind}: head segment {1e3 * t_c:.1f} us, two launches {1e3 * t_u:.1f} us (warm replay); h {eh:.2e} out {eo:.2e}; vs unfused h {relerr(hout, h2):.1e} out {relerr(out, o2):.1e}")
