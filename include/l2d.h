@@ -202,7 +202,15 @@ enum {
  *   p6 / p7 GEGLU projection (LayerNorm gamma / beta folded, value / gate rows interleaved as for L2D_OP_ROWGEMM epi 1) / bias
  *   p8 / p11 FF2 weights / bias   p12 / p13 proj_out weights / bias   p9 / p10, i24..i29 GroupNorm statistics of `out` as
  *   L2D_OP_IGEMM (T % 32 == 0)
- *   i0 M i1 C i2 lda i3 ldr1 i4 ldr2 i5 ldo   f0 eps of the LayerNorm
+ *   i0 M i1 C i2 lda i3 ldr1 i4 ldr2 i5 ldo i6 = 0   f0 eps of the LayerNorm
+ *   i6 = 1: HEAD SEGMENT, two dependent layers in one launch (attention.py:102-110,221-250; motion_module.py:273-279,401-427):
+ *                h = A(norm?(x)) + bA (+ resA) -> p2;   out = B(LayerNorm(h)) + bB, i7 passes of C packed rows each
+ *   p0 x [M][i2] half   p1 resA [M][i3] half or 0   p2 h out [M][i4] half   p3 out [M][i5] half: the first (i7 - i8) passes, C columns each
+ *   p4 / p5 layer A weights (fragment order; a GroupNorm's affine folded) / fp32 bias   p6 / p7 layer B weights (LayerNorm folded) /
+ *   fp32 bias or 0   p8 outT half: with i8 = 1 the LAST pass is stored transposed [sample][channel][i9] (V^T), l0 elements between
+ *   samples   p14 GroupNorm prologue on x: int64 [samples][G][2] fixed-point statistics filled by x's producers (as L2D_OP_ROWGEMM
+ *   prologue 2), or 0   i7 passes (1 | 3) i8 transposed last pass (needs i7 = 3) i9 ldt i10 T tokens per sample i11 G
+ *   f0 eps of the LayerNorm f1 eps of the GroupNorm
  */
 enum {
     L2D_OP_IGEMM = 1,
