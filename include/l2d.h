@@ -239,6 +239,7 @@ enum {
     L2D_OP_PCONV = 24,
     L2D_OP_WSGEMM = 25,
     L2D_OP_ROWCHAIN = 26,
+    L2D_OP_CCONV = 27,
 };
 
 typedef struct l2d_op {

@@ -55,6 +55,7 @@ static int run_one(const l2d_op *op, hipStream_t s) {
         case L2D_OP_PCONV: return l2d_launch_pconv(op, s);
         case L2D_OP_WSGEMM: return l2d_launch_wsgemm(op, s);
         case L2D_OP_ROWCHAIN: return l2d_launch_rowchain(op, s);
+        case L2D_OP_CCONV: return l2d_launch_cconv(op, s);
         case L2D_OP_COPY: {
             if (!op->p[0] || !op->p[1] || op->l[0] <= 0) {
                 l2d_set_error("copy(tag %d): invalid arguments", op->tag);

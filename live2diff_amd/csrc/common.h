@@ -56,6 +56,7 @@ int l2d_launch_rowgemm(const l2d_op *op, hipStream_t s);
 int l2d_launch_pconv(const l2d_op *op, hipStream_t s);
 int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s);
 int l2d_launch_rowchain(const l2d_op *op, hipStream_t s);
+int l2d_launch_cconv(const l2d_op *op, hipStream_t s);
 
 #ifdef __HIPCC__
 // SiLU / GELU are evaluated per output element inside GEMM epilogues and the GroupNorm apply pass (tens of millions of

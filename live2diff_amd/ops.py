@@ -202,6 +202,8 @@ def gn_target(op, acc_ptr: int, **kw) -> bool:
         return wsgemm_gn_target(op, acc_ptr, **kw)
     if op.kind == _lib.OP_ROWCHAIN:
         return rowchain_gn_target(op, acc_ptr, **kw)
+    if op.kind == _lib.OP_CCONV:
+        return cconv_gn_target(op, acc_ptr, **kw)
     return False
 
 
@@ -628,6 +630,123 @@ def wsgemm_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) 
     NW, NT, ntr, epi, M = op.i[9], op.i[10], op.i[21], op.i[19], op.i[13]
     bno = NW * NT * 32
     if T % 32 or M % T or ntr or epi == 1 or G > 32 or (cpg | choff) & 1 or 64 * NW < bno // 2:
+        return False
+    if op.p[9] and (op.i[24], op.i[25]) != (T, G):
+        return False
+    slot = 0 if not op.p[9] else (1 if not op.p[10] else -1)
+    if slot < 0:
+        return False
+    op.p[9 + slot] = int(acc_ptr)
+    op.i[24], op.i[25] = int(T), int(G)
+    op.i[26 + 2 * slot], op.i[27 + 2 * slot] = int(cpg), int(choff)
+    return True
+
+
+# ----------------------------------------------------------------------------- cconv (csrc/cconv.hip, round 6)
+CCONV_RING = 9          # weight ring depth of the kernel in k steps: the packed tensor is padded by this many 2 KB steps
+
+
+def pack_cconv(w: torch.Tensor, KG: int) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] (Cout % 64 == 0; Cin padded to a multiple of 64) -> the weight STREAMS of cconv.hip: for every
+    (64-channel tile n64, K group kg) one contiguous sequence [chunk c][tap t][u < 4 / KG][half i < 2][64 lanes][8 halfs] holding
+    W[64 n64 + 32 i + lane % 32][tap t][64 c + 16 (u KG + kg) + 8 (lane // 32) + e] -- two A operands of
+    v_mfma_f32_32x32x16_f16 per k step, in exactly the order a compute wave consumes them.  Padded with CCONV_RING k steps of
+    zeros (the ring of a block's last k steps requests beyond its slice)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cout % 64 == 0 and KG in (1, 2, 4)
+    cinp = round_up(cin, 64)
+    wp = torch.zeros(cout, 9, cinp, dtype=torch.float16, device=w.device)
+    wp[:, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, 9, cin).to(torch.float16)
+    upt = 4 // KG
+    # [n64][i][r32][t][c][u][kg][lh][e] -> [n64][kg][c][t][u][i][lh][r32][e]
+    v = wp.view(cout // 64, 2, 32, 9, cinp // 64, upt, KG, 2, 8).permute(0, 6, 4, 3, 5, 1, 7, 2, 8).contiguous().view(-1)
+    return torch.cat([v, torch.zeros(CCONV_RING * 1024, dtype=torch.float16, device=w.device)])
+
+
+def unpack_cconv(packed: torch.Tensor, cout: int, cinp: int, KG: int) -> torch.Tensor:
+    """inverse of pack_cconv (tests): -> [Cout, 9, CinP]"""
+    upt = 4 // KG
+    v = packed[:cout * 9 * cinp].view(cout // 64, KG, cinp // 64, 9, upt, 2, 2, 32, 8)
+    return v.permute(0, 5, 7, 3, 2, 4, 1, 6, 8).reshape(cout, 9, cinp)
+
+
+def cconv_ok(H: int, W: int, Nout: int, C1: int, C2: int = 0) -> bool:
+    """Shapes cconv.hip takes: whole 8 x 16 patches of OUTPUT pixels, 64-channel chunks per input, 64-channel output tiles."""
+    return H % 8 == 0 and W % 16 == 0 and Nout % 64 == 0 and C1 % 64 == 0 and C1 > 0 and C2 % 64 == 0
+
+
+def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int):
+    """(CG, KG, NLD, S) for a cconv launch: the widest channel tile that still yields >= ~200 blocks with a K split of whole
+    64-channel chunks; KG = 4 / CG keeps four compute waves per block.  L2D_CCONV_FORCE="CG,KG,NLD,S" overrides (tuning)."""
+    force = os.environ.get("L2D_CCONV_FORCE")
+    if force:
+        cg, kg, nld, S = (int(v) for v in force.split(","))
+        return cg, kg, nld, max(1, min(S, CinP // 64))
+    npat = B * (H // 8) * (W // 16)
+    nch = CinP // 64
+    best = None
+    for cg, kg, nld in ((2, 2, 1), (1, 4, 2)):
+        if Nout % (64 * cg):
+            continue
+        tiles = npat * (Nout // (64 * cg))
+        for S in range(1, min(nch, 8) + 1):
+            blocks = tiles * S
+            if blocks > 256 and S > 1:
+                break
+            # cost model (cycles): the k loop of the longest slice + per-slab tail of the last arriver + fixed; two rounds if > 256 blocks
+            chunks = -(-nch // S)
+            loop = chunks * (9 * 4 // kg) * 8 * 32 / 0.7
+            tail = (S - 1 if S > 1 else 0) * (2100 if cg == 2 else 1100) + (1500 if S > 1 else 0)
+            rounds = -(-blocks // 256)
+            cost = rounds * (loop + 6000 + tail)
+            if best is None or cost < best[0]:
+                best = (cost, (cg, kg, nld, S))
+    return best[1]
+
+
+def cconv_sizes(B: int, H: int, W: int, Nout: int, CG: int, S: int):
+    """(fp32 workspace elements, int32 counters) of a split-K cconv launch: one 128 x 64 CG slab per (tile, slice)"""
+    tiles = B * (H // 8) * (W // 16) * (Nout // (64 * CG))
+    return tiles * S * 128 * 64 * CG, tiles
+
+
+def cconv(x1, w, out, *, B, H, W, C1, ldx1, Nout, ldo, KG, x2=None, C2=0, ldx2=0, ups=0, bias=None, rowbias=None, ldrb=0,
+          rows_per_bias=0, res=None, ldr=0, sched=None, ws=None, cnt=None, cnt_off=0):
+    """3x3 stride-1 pad-1 conv with the activation patch resident in LDS and register-streamed weights (csrc/cconv.hip).
+    H x W = OUTPUT resolution; ups = 1: the input is [B, H/2, W/2, C] and is up-sampled x2 (nearest) on the fly (Upsample3D).
+    `w` = pack_cconv(weight, KG).  sched = (CG, KG, NLD, S) or None for cconv_schedule (its KG must equal the packing's);
+    S > 1 needs `ws` / `cnt` (cconv_sizes)."""
+    op = L2dOp()
+    op.kind = _lib.OP_CCONV
+    CinP = C1 + C2
+    if sched is None:
+        sched = cconv_schedule(B, H, W, Nout, CinP)
+    CG, KG_, NLD, S = sched
+    assert KG_ == KG, (sched, KG)
+    assert w.dtype == torch.float16 and w.numel() == Nout * 9 * CinP + CCONV_RING * 1024, (w.shape, Nout, CinP)
+    zp = zero_page(x1.device)
+    op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), (_ptr(x2) if x2 is not None else None), _ptr(_h(w))
+    op.p[3], op.p[4], op.p[5] = _ptr(bias), _ptr(rowbias), (_ptr(_h(res)) if res is not None else None)
+    op.p[6], op.p[7] = _ptr(_h(out)), _ptr(zp)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == Nout
+    if S > 1:
+        need_ws, need_cnt = cconv_sizes(B, H, W, Nout, CG, S)
+        assert ws is not None and ws.dtype == torch.float32 and ws.numel() >= need_ws, (need_ws,)
+        assert cnt is not None and cnt.dtype == torch.int32 and cnt.numel() >= cnt_off + need_cnt
+        op.p[11] = _ptr(cnt) + 4 * cnt_off
+        op.p[12] = _ptr(ws)
+    vals = {1: C1, 2: C2, 3: ldx1, 4: ldx2, 5: CinP, 6: B, 7: H, 8: W, 9: CG, 10: KG, 11: NLD, 12: S, 13: ups, 14: Nout, 15: ldo,
+            16: ldr, 17: ldrb, 18: rows_per_bias}
+    for j, v in vals.items():
+        op.i[j] = int(v)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt)
+
+
+def cconv_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:
+    """GroupNorm statistics of a cconv launch's output for a consumer GroupNorm (a patch never straddles samples)."""
+    assert op.kind == _lib.OP_CCONV
+    if T != op.i[7] * op.i[8] or G > 32 or (cpg | choff) & 1:
         return False
     if op.p[9] and (op.i[24], op.i[25]) != (T, G):
         return False
