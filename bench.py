@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
-MFMA_KERNELS = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel", "rowchain_kernel", "flash_attn_kernel")   # kernel families priced against the MFMA roofline
+MFMA_KERNELS = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "cconv_kernel", "wsgemm_kernel", "rowchain_kernel", "flash_attn_kernel")   # kernel families priced against the MFMA roofline
 
 
 # (height, width, denoise steps, window L) of the BASELINE.json configurations the GPU leg can run
@@ -52,6 +52,10 @@ def op_work(op, kinds):
         B, H, W_, C, Nout = i[6], i[7], i[8], i[1] + i[2], i[14]
         M = B * H * W_
         return 2.0 * M * Nout * 9 * C, 2.0 * (M * C + Nout * 9 * C + M * Nout)
+    if k == kinds.OP_CCONV:
+        B, H, W_, C, Nout, ups = i[6], i[7], i[8], i[1] + i[2], i[14], i[13]
+        M = B * H * W_
+        return 2.0 * M * Nout * 9 * C, 2.0 * ((M >> (2 * ups)) * C + Nout * 9 * C + M * Nout)
     if k == kinds.OP_ROWGEMM:
         M, K, Nout = i[0], i[1], i[2]
         return 2.0 * M * Nout * K, 2.0 * (M * K + Nout * K + M * (Nout // 2 if i[6] == 1 else Nout))
@@ -86,7 +90,7 @@ def op_work(op, kinds):
 KIND_NAMES = {1: "igemm_kernel", 2: "gn_stats_kernel", 3: "gn_apply_kernel", 4: "layernorm_kernel", 5: "flash_attn_kernel",
               6: "tattn_stream_kernel", 7: "tattn_warmup_kernel", 8: "skinny_linear_kernel", 9: "timestep_embed_kernel",
               10: "nchw_to_nhwc_kernel", 11: "nhwc_to_nchw_kernel", 12: "lcm_step_kernel", 13: "copy", 23: "rowgemm_kernel", 24: "pconv_kernel", 25: "wsgemm_kernel",
-              26: "rowchain_kernel"}
+              26: "rowchain_kernel", 27: "cconv_kernel"}
 
 
 def per_kernel_breakdown(unet, reps=5):
@@ -152,6 +156,8 @@ def op_dims(op, kinds):
                 f"b{max(1, i[20])} S{max(1, i[21])} t{i[22] & 15} v{i[23]} o{i[22] >> 4}")
     if op.kind == kinds.OP_PCONV:
         return f"B{i[6]} H{i[7]} W{i[8]} C{i[1] + i[2]} N{i[14]} patch{i[9]}x{i[10]} o{i[11]}"
+    if op.kind == kinds.OP_CCONV:
+        return f"B{i[6]} H{i[7]} W{i[8]} C{i[1] + i[2]} N{i[14]} u{i[13]} cg{i[9]} kg{i[10]} l{i[11]} S{max(1, i[12])}"
     if op.kind == kinds.OP_ROWGEMM:
         i = op.i
         return f"M{i[0]} N{i[2]} K{i[1]} e{i[6]} p{i[7]} w{i[12]} t{i[13]} m{i[14]} tr{i[15]}"
@@ -643,7 +649,7 @@ def main():
         my_frac = result["roofline"]["frac"]
         # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
         # rate is the figure comparable with the single igemm family of rounds 1-2
-        GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "wsgemm_kernel", "rowchain_kernel")
+        GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "cconv_kernel", "wsgemm_kernel", "rowchain_kernel")
         gem = [rows[k_] for k_ in GEMM_FAMILIES if k_ in rows]
         if gem:
             gms, gfl = sum(g_["ms"] for g_ in gem), sum(g_["flops"] for g_ in gem)
@@ -661,7 +667,7 @@ def main():
             small = []
             for j_ in range(len(st_.pl)):
                 o_ = st_.pl[j_]
-                m_ = {_l.OP_IGEMM: o_.i[13], _l.OP_ROWGEMM: o_.i[0], _l.OP_WSGEMM: o_.i[13]}.get(o_.kind)
+                m_ = {_l.OP_IGEMM: o_.i[13], _l.OP_ROWGEMM: o_.i[0], _l.OP_WSGEMM: o_.i[13], _l.OP_CCONV: o_.i[6] * o_.i[7] * o_.i[8]}.get(o_.kind)
                 if m_ is not None and 0 < m_ <= 512:
                     small.append(o_)
             if small:

@@ -60,7 +60,18 @@ struct CConvArgs {
     int Nout, ldo, ldr, ldrb, rows_per_bias;
     int npx, npy, npat, ntn, S, cps, crem, nwg;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
+#ifdef L2D_PROBES
+    unsigned long long *probe;     // analysis builds: 32 s_memtime stamps per block (tools/cconv_stamps.py)
+#endif
 };
+
+#ifdef L2D_PROBES
+static unsigned long long *g_cconv_probe = nullptr;
+extern "C" void l2d_cconv_set_probe(void *p) { g_cconv_probe = (unsigned long long *)p; }
+#define CC_STAMP(i) do { if (a.probe && lane == 0) a.probe[(unsigned long long)blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CC_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 constexpr int CC_PH = 8, CC_PW = 16, CC_PWH = CC_PW + 2, CC_NPIX = (CC_PH + 2) * CC_PWH, CC_NPIXP = 192, CC_SEG = 3;
@@ -156,17 +167,23 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                 }
             }
         };
+        if (l == 0) CC_STAMP(10);
         issue_chunk(0);
+        if (l == 0) CC_STAMP(11);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == 0) CC_STAMP(12);
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
         for (int c = 0; c < n; ++c) {
             if (c + 1 < n) issue_chunk(c + 1);               // (its buffer was chunk c - 1's: every wave passed the previous barrier)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (l == 0 && c < 6) CC_STAMP(24 + c);           // chunk c + 1 landed (this loader's share)
             __builtin_amdgcn_s_barrier();                    // chunk c + 1 has landed; the compute waves are done with chunk c
         }
+        if (l == 0) CC_STAMP(13);
     } else {
         // ---------------------------------------------------------------------------------------------- compute waves
         // weight stream of (channel tile n64, K group kg): [chunk][tap][u < UPT][half i < 2][64 lanes][8 halfs], k step kk = u KG + kg
+        if (wave == 0) CC_STAMP(0);
         const int n64 = tile_n * CG + cgw;
         const h16 *wp = a.w + (((long long)n64 * KG + kgw) * a.nch + c0) * (SPC * 1024);
         const int wlane = lane * 8;
@@ -182,9 +199,11 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         __builtin_amdgcn_sched_barrier(0);
         // this lane's fragment slot of k step kk = kg (u = 0), tap (0, 0), token tile 0: channel slot q = 2 kk + lh
         const int lbase = ((2 * kgw + lh) * CC_NPIXP + trow * CC_PWH + tcol) * 8;
+        if (wave == 0) CC_STAMP(1);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
         asm volatile("" ::: "memory");
+        if (wave == 0) CC_STAMP(2);
         for (int c = 0; c < n; ++c) {
             const h16 *pb = smem + (c & 1) * CC_PBUFH + lbase;
             // k step s = (tap t = s / UPT, u = s % UPT): fragment reads at pb + off(s) + token tile * 2 patch rows.  The reads of
@@ -213,9 +232,11 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this chunk has returned
+            if (wave == 0 && c < 8) CC_STAMP(16 + c);        // chunk c done (issue side)
             __builtin_amdgcn_s_barrier();                    // done with chunk c's buffer; chunk c + 1 has landed
             asm volatile("" ::: "memory");
         }
+        if (wave == 0) CC_STAMP(3);
     }
 
     // ------------------------------------------------------------------------------------------------- K groups meet
@@ -285,6 +306,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
             else if (KG > 2) gather(std::integral_constant<int, 3 % KG>{});
         }
         __syncthreads();                                     // (the parked partials are dead: the staged tile may overwrite them)
+        if (wave == 0) CC_STAMP(4);
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -319,6 +341,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         if (tid == 0) *flag = atomicAdd(a.cnt + tile, 1u);
         __syncthreads();
         const bool last = (*flag == (unsigned int)(a.S - 1));
+        if (wave == 0) CC_STAMP(5);
         if (!last) return;
         if (tid == 0) atomicExch(a.cnt + tile, 0u);             // ready for the next launch that uses this counter
         if (cons) {
@@ -343,6 +366,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
             }
         }
         __syncthreads();
+        if (wave == 0) CC_STAMP(6);
     }
 
     // ------------------------------------------------------------------------------------------------- epilogue
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         }
     }
     __syncthreads();
+    if (wave == 0) CC_STAMP(7);
     const bool gn = a.gn1 != nullptr;
     float gs[4], gq[4];
 #pragma unroll
@@ -425,6 +450,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         l2d_gn_flush(a.gn1, a.gnG, a.cpg1 >> 1, a.choff1 >> 1, bb, chs1, chs2, n0 >> 1, BN >> 1, tid);
         l2d_gn_flush(a.gn2, a.gnG, a.cpg2 >> 1, a.choff2 >> 1, bb, chs1, chs2, n0 >> 1, BN >> 1, tid);
     }
+    if (wave == 0) CC_STAMP(8);
 }
 
 template <int CG, int KG, int NLD>
@@ -453,6 +479,9 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
     a.ups = op->i[13] ? 1 : 0;
     a.Nout = op->i[14]; a.ldo = op->i[15]; a.ldr = op->i[16]; a.ldrb = op->i[17]; a.rows_per_bias = op->i[18];
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
+#ifdef L2D_PROBES
+    a.probe = g_cconv_probe;
+#endif
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
     const bool geo = (CG == 2 && KG == 2 && (NLD == 1 || NLD == 2)) || (CG == 1 && KG == 4 && (NLD == 1 || NLD == 2)) ||
                      (CG == 4 && KG == 1 && NLD == 1);

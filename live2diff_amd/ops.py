@@ -675,33 +675,49 @@ def cconv_ok(H: int, W: int, Nout: int, C1: int, C2: int = 0) -> bool:
     return H % 8 == 0 and W % 16 == 0 and Nout % 64 == 0 and C1 % 64 == 0 and C1 > 0 and C2 % 64 == 0
 
 
-def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int):
-    """(CG, KG, NLD, S) for a cconv launch: the widest channel tile that still yields >= ~200 blocks with a K split of whole
-    64-channel chunks; KG = 4 / CG keeps four compute waves per block.  L2D_CCONV_FORCE="CG,KG,NLD,S" overrides (tuning)."""
+def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int, KG: Optional[int] = None):
+    """(CG, KG, NLD, S) for a cconv launch: channel tile (64 CG), K groups per tile (CG KG = 4 compute waves), loader waves and
+    K slices of whole 64-channel chunks, from a cost model fitted to tools/cconv_time.py / tools/cconv_stamps.py (MI355X): the k loop
+    of the longest slice at ~0.7 of the matrix rate, a fixed prologue / epilogue, per split the slab publish and the last arriver's
+    sum, and a second round of blocks beyond one per CU.  `KG`: the packing's K-group count when it is already fixed (the warm-up
+    plan shares the stream plan's packed weights).  L2D_CCONV_FORCE="CG,KG,NLD,S" overrides (tuning)."""
     force = os.environ.get("L2D_CCONV_FORCE")
+    nch = CinP // 64
     if force:
         cg, kg, nld, S = (int(v) for v in force.split(","))
-        return cg, kg, nld, max(1, min(S, CinP // 64))
+        if (KG is None or kg == KG) and Nout % (64 * cg) == 0:
+            return cg, kg, nld, max(1, min(S, nch))
     npat = B * (H // 8) * (W // 16)
-    nch = CinP // 64
     best = None
-    for cg, kg, nld in ((2, 2, 1), (1, 4, 2)):
-        if Nout % (64 * cg):
+    for cg, kg, nld in ((2, 2, 2), (1, 4, 2)):
+        if Nout % (64 * cg) or (KG is not None and kg != KG):
             continue
         tiles = npat * (Nout // (64 * cg))
         for S in range(1, min(nch, 8) + 1):
             blocks = tiles * S
             if blocks > 256 and S > 1:
                 break
-            # cost model (cycles): the k loop of the longest slice + per-slab tail of the last arriver + fixed; two rounds if > 256 blocks
             chunks = -(-nch // S)
-            loop = chunks * (9 * 4 // kg) * 8 * 32 / 0.7
-            tail = (S - 1 if S > 1 else 0) * (2100 if cg == 2 else 1100) + (1500 if S > 1 else 0)
+            loop = chunks * (9 * 4 // kg) * 8 * 32 / (0.72 if kg == 2 else 0.45)
+            tail = ((S - 1) * (2300 if cg == 2 else 1200) + 6000) if S > 1 else 0
             rounds = -(-blocks // 256)
-            cost = rounds * (loop + 6000 + tail)
+            cost = rounds * (loop + 14000 + tail)
             if best is None or cost < best[0]:
                 best = (cost, (cg, kg, nld, S))
+    assert best is not None, (B, H, W, Nout, CinP, KG)
     return best[1]
+
+
+def cconv_wanted(B: int, H: int, W: int, Cin: int, Nout: int, ups: int = 0) -> bool:
+    """Whether the plan gives a 3x3 stride-1 conv to cconv.hip (H x W = output resolution).  Measured at cfg-2 against the kernel
+    each launch had before (tools/cconv_time.py, profiles/round6_a_cconv_time.log): the up-samplers 1.4-1.5 x (igemm), the resnet
+    convs of the 640- / 1280-wide levels 1.0-1.35 x (wsgemm); the 320-wide level keeps the patch conv (0.87 x: 320 blocks of one
+    64-channel tile are two rounds over the chip).  L2D_CCONV=0 switches the kernel off (A/B)."""
+    if os.environ.get("L2D_CCONV", "1") == "0" or not cconv_ok(H, W, Nout, Cin):
+        return False
+    if ups:
+        return True
+    return Nout >= 640 and B * H * W >= 512
 
 
 def cconv_sizes(B: int, H: int, W: int, Nout: int, CG: int, S: int):

@@ -264,9 +264,27 @@ class HipStreamingUNet:
             lvl = int(name.split(".")[1])
             return cfg.num_levels - 1 - lvl if name.startswith("up_blocks") else lvl
 
-        def conv3ws(name, lvl):
-            """resnet 3x3 conv: weight-streaming packing at the few-token levels, else the implicit-GEMM / patch-conv packing"""
+        def conv3cc(name, lvl_out, ups=0) -> bool:
+            """3x3 stride-1 conv whose OUTPUT lives at level `lvl_out`: the patch-resident / register-streamed packing of cconv.hip
+            where the plan wants that kernel (ops.cconv_wanted: measured per shape class); the K-group count of the packing is the
+            stream plan's (ops.cconv_schedule on the stream batch), the warm-up plan re-uses it"""
             cw = sd[name + ".weight"]
+            if lvl_out is None:
+                return False
+            Ho, Wo = self.h >> lvl_out, self.w >> lvl_out
+            if cw.shape[1] % 64 or not ops.cconv_wanted(self.N, Ho, Wo, cw.shape[1], cw.shape[0], ups):
+                return False
+            kg = ops.cconv_schedule(self.N, Ho, Wo, cw.shape[0], cw.shape[1])[1]
+            W[name + ".cw"] = ops.pack_cconv(g(name + ".weight"), kg)
+            W[name + ".b"] = ops.f32(g(name + ".bias"))
+            return True
+
+        def conv3ws(name, lvl):
+            """resnet 3x3 conv: cconv packing where that kernel is wanted, weight-streaming packing at the few-token levels, else the
+            implicit-GEMM / patch-conv packing"""
+            cw = sd[name + ".weight"]
+            if conv3cc(name, lvl):
+                return
             # (the kernel's loader walks 8 NL pixels per DMA instruction with at most two row wraps: W >= 8, wsgemm.hip; narrower
             # levels -- tall / narrow latents such as 64 x 32 -- stay on the implicit-GEMM / patch kernels like in round 3)
             if (lvl is not None and (self.w >> lvl) >= 8 and cw.shape[0] % 32 == 0 and cw.shape[1] % 64 == 0
@@ -393,7 +411,8 @@ class HipStreamingUNet:
                     spatial(f"up_blocks.{i}.attentions.{j}")
                 motion(f"up_blocks.{i}.motion_modules.{j}", rev[i])
             if i != nl - 1:
-                conv3(f"up_blocks.{i}.upsamplers.0.conv")
+                if not conv3cc(f"up_blocks.{i}.upsamplers.0.conv", nl - 2 - i, ups=1):       # (output: one level up)
+                    conv3(f"up_blocks.{i}.upsamplers.0.conv")
         norm("conv_norm_out"); conv3("conv_out")
         W["temb_all.w"] = torch.cat(temb_w, 0).contiguous()          # [sum Cout, 4*c0]
         W["temb_all.b"] = torch.cat(temb_b, 0).contiguous()
@@ -407,7 +426,7 @@ class HipStreamingUNet:
         return sum(t.numel() * t.element_size() for t in self.W.values())
 
     # ------------------------------------------------------------------ packed-weight cache
-    PACK_FORMAT = 3      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
+    PACK_FORMAT = 4      # bump when _pack_weights changes layout (packed conv / GEGLU order, fused projections, ...)
 
     def save_packed(self, path) -> None:
         """Write the packed weights (what `_pack_weights` produced from the reference-keyed state dict: merged
@@ -474,7 +493,7 @@ class HipStreamingUNet:
         return dict(ws_levels=[bool(v) for v in self.ws_levels],
                     old_levels=[((self.h >> l) * (self.w >> l)) % 32 != 0 for l in range(nl)],
                     ws_skip=sorted(ops._WS_SKIP), ws_large=sorted(ops._WS_LARGE), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
-                    rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rowchain=os.environ.get("L2D_ROWCHAIN", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
+                    cconv=os.environ.get("L2D_CCONV", "1"), rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rowchain=os.environ.get("L2D_ROWCHAIN", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
                     rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))
 
     @staticmethod
@@ -614,6 +633,30 @@ class HipStreamingUNet:
             return out
 
         def conv3(x: _Act, name, stride=1, ups=0, epi=0, res: Optional[_Act] = None, rowbias=None) -> _Act:
+            if (name + ".cw") in W:
+                # patch-resident activations + register-streamed weights (cconv.hip): resnet convs of the wide levels, up-samplers
+                assert stride == 1 and epi == 0
+                cout = W[name + ".b"].numel()
+                Ho, Wo = x.H << ups, x.W << ups
+                out = new_act(cout, Ho, Wo)
+                kg = ops.cconv_schedule(self.N, Ho, Wo, cout, x.C)[1]          # (the packing's: decided on the stream batch)
+                sched = ops.cconv_schedule(B, Ho, Wo, cout, x.C, KG=kg)
+                ws_buf, kw = None, {}
+                if sched[3] > 1:
+                    n_ws, n_cnt = ops.cconv_sizes(B, Ho, Wo, cout, sched[0], sched[3])
+                    ws_buf = ar.alloc(n_ws, torch.float32)
+                    kw = dict(ws=ws_buf, cnt=st.sk_cnt, cnt_off=st.sk_used)
+                    st.sk_used += n_cnt
+                if rowbias is not None:
+                    kw.update(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(Ho * Wo if mode == "stream" else B * Ho * Wo))
+                op_ = add(ops.cconv(x.buf, W[name + ".cw"], out.buf, B=B, H=Ho, W=Wo, C1=x.C, ldx1=x.C, Nout=cout, ldo=cout, KG=kg, ups=ups,
+                                    bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
+                                    sched=sched, **kw))
+                if rowbias is not None:
+                    op_.p[4] = st.temb_all.data_ptr() + 4 * rowbias
+                ar.release(ws_buf)
+                out.producer = op_
+                return out
             if use_ws(name):
                 # resnet conv at a few-token level: weight-streaming GEMM over (tap, channel chunk) stages (wsgemm.hip)
                 assert stride == 1 and not ups and epi == 0

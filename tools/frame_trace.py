@@ -13,7 +13,7 @@ import csv
 import sqlite3
 import sys
 
-FAMILIES = ("igemm_splitk_epilogue", "igemm_kernel", "rowgemm_kernel", "rowchain", "wsgemm_kernel", "pconv_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel", "flash_attn_kernel",
+FAMILIES = ("igemm_splitk_epilogue", "igemm_kernel", "rowgemm_kernel", "rowchain", "wsgemm_kernel", "pconv_kernel", "cconv_kernel", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel", "flash_attn_kernel",
             "tattn_stream", "tattn_warmup_kernel", "skinny_linear_kernel", "timestep_embed_kernel", "nchw_to_nhwc_kernel",
             "nhwc_to_nchw_kernel", "lcm_step_kernel")
 

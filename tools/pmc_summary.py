@@ -13,7 +13,7 @@ import json
 import sqlite3
 import sys
 
-PRODUCT = ("igemm", "rowgemm", "rowchain", "wsgemm", "pconv", "gn_", "layernorm", "flash_attn", "flash_ring", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step")
+PRODUCT = ("igemm", "rowgemm", "rowchain", "wsgemm", "pconv", "cconv", "gn_", "layernorm", "flash_attn", "flash_ring", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step")
 
 
 def short(name):
@@ -25,7 +25,7 @@ def short(name):
 def family(name):
     if "rowchain_" in name:
         return "rowchain_kernel"
-    for p in ("igemm_splitk_epilogue", "igemm_kernel", "rowgemm_kernel", "wsgemm_kernel", "pconv_kernel", "gn_stats", "gn_apply", "layernorm", "flash_attn", "flash_ring", "tattn_stream", "tattn_warmup",
+    for p in ("igemm_splitk_epilogue", "igemm_kernel", "rowgemm_kernel", "wsgemm_kernel", "pconv_kernel", "cconv_kernel", "gn_stats", "gn_apply", "layernorm", "flash_attn", "flash_ring", "tattn_stream", "tattn_warmup",
               "skinny_linear", "timestep_embed", "nchw_to_nhwc", "nhwc_to_nchw", "lcm_step"):
         if p in name:
             return p + ("_kernel" if not p.endswith("kernel") and p != "igemm_splitk_epilogue" else "")

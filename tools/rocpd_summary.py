@@ -11,7 +11,7 @@ import collections
 import sqlite3
 import sys
 
-PRODUCT = ("igemm", "rowgemm", "rowchain", "wsgemm", "pconv", "gn_", "layernorm", "flash_attn", "flash_ring", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step", "copy_kernel")
+PRODUCT = ("igemm", "rowgemm", "rowchain", "wsgemm", "pconv", "cconv", "gn_", "layernorm", "flash_attn", "flash_ring", "tattn", "skinny", "timestep", "nchw", "nhwc", "lcm_step", "copy_kernel")
 
 
 def main():
