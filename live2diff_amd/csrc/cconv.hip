@@ -32,9 +32,12 @@
 //     arrival counter, last block sums in the fixed order 0..S-1: bit-repeatable);
 //   * epilogue = pconv.hip's: fp32 bias + per-sample time-embedding row -> fp16 -> LDS -> whole rows (16 B per lane) with the
 //     residual added in fp16, GroupNorm statistics of the output as fixed-point integer atomics.
-// The 32 tokens of an MFMA token tile are two patch rows of 16 pixels; inside the tile the second row's lanes are rotated by two
-// pixels so that, with the 18-pixel row pitch of the haloed patch, the two rows of every ds_read_b128 lane group fall on
-// disjoint 16-byte bank slots (conflict-free for every tap; the epilogue undoes the rotation when it stages the tile).
+// Patch image in LDS: pixel-major, 128 bytes (64 channels) per pixel, so one DMA instruction moves eight whole 128-byte lines (a
+// slot-major image costs 64 lines of 16 useful bytes per instruction: measured ~150 cycles per instruction whatever the number of
+// loaders); the 16-byte channel slot q of a pixel sits at position q ^ ((patch column >> 1) & 7).  The 32 tokens of an MFMA token tile
+// are two patch rows of 16 pixels: with that key the 16 lanes of every ds_read_b128 lane group hit 16 distinct bank slots for every tap
+// (checked exhaustively, tests/test_host_logic.py), and because the key depends on the column only, a tap's row offset and the token
+// tile are IMMEDIATE offsets of the read: three base registers per k sub-step (one per dx), no address arithmetic in the loop.
 // Rounding points: conv output (+ bias) -> fp16, residual add in fp16 (as igemm / pconv / wsgemm).
 // Built WITHOUT packed fp32 VALU instructions like the rest of the library (csrc/Makefile).
 #include <type_traits>
@@ -75,8 +78,10 @@ extern "C" void l2d_cconv_set_probe(void *p) { g_cconv_probe = (unsigned long lo
 
 namespace {
 constexpr int CC_PH = 8, CC_PW = 16, CC_PWH = CC_PW + 2, CC_NPIX = (CC_PH + 2) * CC_PWH, CC_NPIXP = 192, CC_SEG = 3;
-constexpr int CC_PBUFH = 8 * CC_NPIXP * 8;          // halfs per patch buffer: 8 channel slots x 192 pixels x 16 B = 24 KB
+constexpr int CC_PBUFH = CC_NPIXP * 64;             // halfs per patch buffer: 192 pixels x 64 channels = 24 KB
 constexpr int CC_RING = 9;                          // weight ring depth in k steps (2 KB each)
+constexpr int CC_NBUF = 3;                          // patch buffers: the loaders run two chunks ahead of the compute waves
+constexpr int CC_PAR_OFF = 100 * 1024;              // byte offset of the epilogue parameters (bias | time-embedding row) + flag word in LDS
 }  // namespace
 
 // LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear at the LDS byte address in M0) as inline asm: with the builtin in
@@ -87,6 +92,23 @@ __device__ __forceinline__ void cc_dma16(unsigned long long gsrc, unsigned lds_d
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void cc_dma4(unsigned long long gsrc, unsigned lds_dst) {       // 4 bytes per lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+#ifndef CC_WNT
+#define CC_WNT 0
+#endif
+__device__ __forceinline__ h16x8 cc_wload(const h16 *p) {
+#if CC_WNT
+    return __builtin_nontemporal_load(reinterpret_cast<const h16x8 *>(p));
+#else
+    return l2d_ld8(p);
+#endif
 }
 
 // CG: 64-channel tiles per block; KG: K groups per channel tile; NLD: loader waves
@@ -126,8 +148,8 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
             for (int e = 0; e < 16; ++e) acc[i][mt][e] = 0.f;
 
     const int l32 = lane & 31, lh = lane >> 5;
-    // this lane's token inside a 32-token tile: patch row (l32 >> 4) of the tile's two, pixel ((l32 & 15) - 2 row) mod 16
-    const int trow = l32 >> 4, tcol = ((l32 & 15) - 2 * trow) & 15;
+    // this lane's token inside a 32-token tile: patch row (l32 >> 4) of the tile's two, pixel l32 & 15
+    const int trow = l32 >> 4, tcol = l32 & 15;
     const int kgw = __builtin_amdgcn_readfirstlane(cons ? wave / CG : 0), cgw = __builtin_amdgcn_readfirstlane(cons ? wave - kgw * CG : 0);
 
     if (!cons) {
@@ -136,46 +158,71 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         // patch[(q * 192 + pixel) * 16 B]; pixel p of the haloed patch = (row p / 18, column p % 18), image pixel (y0 - 1 + row,
         // x0 - 1 + column); pixels outside the image (the conv's zero padding) and lanes beyond the patch read the zero page.
         const int l = wave - NCW;
-        unsigned pix2[CC_SEG];                                // 2 x pixel index in the source image (bytes per half)
-        bool okp[CC_SEG];
+        __builtin_amdgcn_s_setprio(3);                       // few instructions, all of them on the compute waves' critical path: win every arbitration
+        constexpr int DPC = 24 / NLD;                        // DMA instructions per loader and chunk
+        static_assert(24 % NLD == 0, "every loader issues the same number of DMA instructions per chunk");
+        // DMA instruction j (0..23) of a chunk moves the eight pixels 8 j .. 8 j + 7 of the haloed patch, one 128-byte line (64 channels)
+        // each: lane -> (pixel 8 j + lane / 8, 16-byte position lane % 8); position pos of pixel p holds channel slot pos ^ key(p),
+        // key = (patch column >> 1) & 7 -- the bank swizzle, applied to the SOURCE because the DMA image is lane-linear.  Pixel p =
+        // (row p / 18, column p % 18) = image pixel (y0 - 1 + row, x0 - 1 + column); pixels outside the image (the conv's zero padding)
+        // and beyond the patch read the zero page.  This loader owns instructions l DPC .. l DPC + DPC - 1.
+        unsigned pix2[DPC], qb[DPC];                         // 2 x pixel index in the source image; byte offset of the channel slot
+        bool okp[DPC];
 #pragma unroll
-        for (int s = 0; s < CC_SEG; ++s) {
-            const int p = s * 64 + lane;
+        for (int jj = 0; jj < DPC; ++jj) {
+            const int p = 8 * (l * DPC + jj) + (lane >> 3);
             const int r = p / CC_PWH, cx = p - r * CC_PWH;
             const int iy = y0 - 1 + r, ix = x0 - 1 + cx;
-            okp[s] = p < CC_NPIX && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
-            pix2[s] = okp[s] ? 2u * (unsigned)((bb * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups)) : 0u;
+            okp[jj] = p < CC_NPIX && iy >= 0 && ix >= 0 && iy < a.H && ix < a.W;
+            pix2[jj] = okp[jj] ? 2u * (unsigned)((bb * a.Hs + (iy >> a.ups)) * a.Ws + (ix >> a.ups)) : 0u;
+            qb[jj] = (unsigned)(((lane & 7) ^ ((cx >> 1) & 7)) * 16);
         }
         const int nc1 = a.C1 >> 6;
         const unsigned lds0 = (unsigned)(size_t)L2D_LPTR(smem);
         const unsigned long long zp = (unsigned long long)a.zero;
-        auto issue_chunk = [&](int c) __attribute__((always_inline)) {      // chunk c0 + c -> buffer c & 1
+        auto issue_chunk = [&](int c, unsigned bufo) __attribute__((always_inline)) {      // chunk c0 + c -> patch buffer at byte offset bufo
             const int cc = c0 + c;
             const bool first = cc < nc1;
             const unsigned long long xb = first ? (unsigned long long)(a.x1 + cc * 64) : (unsigned long long)(a.x2 + (cc - nc1) * 64);   // wave-uniform
             const unsigned ldsel = (unsigned)(first ? a.ldx1 : a.ldx2);
-            const unsigned dst = lds0 + (unsigned)(c & 1) * (CC_PBUFH * 2);
-            unsigned long long srow[CC_SEG];
+            const unsigned dst = lds0 + bufo + (unsigned)l * (DPC * 1024);
 #pragma unroll
-            for (int s = 0; s < CC_SEG; ++s) srow[s] = okp[s] ? xb + pix2[s] * ldsel : zp;     // (32-bit byte offsets: checked by the launcher)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                for (int s = 0; s < CC_SEG; ++s) {
-                    if (NLD > 1 && ((q * CC_SEG + s) % NLD) != l) continue;
-                    cc_dma16(okp[s] ? srow[s] + q * 16 : zp, dst + (q * CC_NPIXP + s * 64) * 16);
-                }
-            }
+            for (int jj = 0; jj < DPC; ++jj)                 // (32-bit byte offsets: checked by the launcher)
+                cc_dma16(okp[jj] ? xb + (pix2[jj] * ldsel + qb[jj]) : zp, dst + jj * 1024);
         };
         if (l == 0) CC_STAMP(10);
-        issue_chunk(0);
-        if (l == 0) CC_STAMP(11);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (l == NLD - 1) {
+            // epilogue parameters of this block's channels -> LDS (bias | this sample's time-embedding row): as cold global loads at the
+            // START of the epilogue they would be a full round trip on the last arriver's critical path.  Older than every patch DMA of
+            // this wave in the in-order queue, so the first counted wait covers them.
+            const float *rb = a.rowbias ? a.rowbias + (long long)((bb * a.H * a.W) / a.rows_per_bias) * a.ldrb : nullptr;
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                if (a.bias) cc_dma4((unsigned long long)(a.bias + n0 + j * 64 + lane), lds0 + CC_PAR_OFF + j * 256);
+                if (rb) cc_dma4((unsigned long long)(rb + n0 + j * 64 + lane), lds0 + CC_PAR_OFF + BN * 4 + j * 256);
+            }
+        }
+        // The loaders run TWO chunks ahead (three patch buffers): the DMAs of chunk c + 2 are in flight while chunk c + 1 lands and chunk
+        // c is consumed; a loader waits for "all but my DPC youngest" (in-order return), never for an empty queue inside the loop.
+        issue_chunk(0, 0);
+        if (n > 1) {
+            issue_chunk(1, CC_PBUFH * 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (l == 0) CC_STAMP(12);
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
+        unsigned bufn = 2 * CC_PBUFH * 2;                     // buffer of chunk c + 2
         for (int c = 0; c < n; ++c) {
-            if (c + 1 < n) issue_chunk(c + 1);               // (its buffer was chunk c - 1's: every wave passed the previous barrier)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c + 2 < n) {
+                issue_chunk(c + 2, bufn);                    // (its buffer was chunk c - 1's: every wave passed the previous barrier)
+                bufn = bufn == (CC_NBUF - 1) * CC_PBUFH * 2 ? 0u : bufn + CC_PBUFH * 2;
+                if (l == 0 && c >= 1 && c < 4) CC_STAMP(13 + c);         // chunk c + 2 issued (stamps 14..16)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (l == 0 && c < 6) CC_STAMP(24 + c);           // chunk c + 1 landed (this loader's share)
             __builtin_amdgcn_s_barrier();                    // chunk c + 1 has landed; the compute waves are done with chunk c
         }
@@ -193,49 +240,86 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         for (int s = 0; s < R; ++s) {
             asm volatile("" : "+s"(wcur));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wr[s][i] = l2d_ld8(wp + (wcur + i * 512) + wlane);
+            for (int i = 0; i < 2; ++i) wr[s][i] = cc_wload(wp + (wcur + i * 512) + wlane);
             wcur += 1024;
         }
         __builtin_amdgcn_sched_barrier(0);
-        // this lane's fragment slot of k step kk = kg (u = 0), tap (0, 0), token tile 0: channel slot q = 2 kk + lh
-        const int lbase = ((2 * kgw + lh) * CC_NPIXP + trow * CC_PWH + tcol) * 8;
+        // this lane's fragment of k step kk = u KG + kg, tap (dy, dx), token tile mt: pixel p = (2 mt + trow + dy) 18 + tcol + dx, channel
+        // slot q = 2 kk + lh at position q ^ key(column): lbase[dx][u] + (dy + 2 mt) * 18 * 64 halfs -- the key depends on dx only
+        int lbase[3][UPT];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int u = 0; u < UPT; ++u)
+                lbase[dx][u] = (trow * CC_PWH + tcol + dx) * 64 + (((2 * (u * KG + kgw) + lh) ^ (((tcol + dx) >> 1) & 7)) * 8);
         if (wave == 0) CC_STAMP(1);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
         asm volatile("" ::: "memory");
         if (wave == 0) CC_STAMP(2);
-        for (int c = 0; c < n; ++c) {
-            const h16 *pb = smem + (c & 1) * CC_PBUFH + lbase;
-            // k step s = (tap t = s / UPT, u = s % UPT): fragment reads at pb + off(s) + token tile * 2 patch rows.  The reads of
-            // step s + 1 are issued in FRONT of step s's MFMAs (they fit under the previous step's last MFMA); the refill of a ring
-            // position follows the four MFMAs that consumed it.  One scheduling region per k step.
-            auto xoff = [](int s_) { const int t = s_ / UPT, u = s_ - t * UPT; return (u * KG * 2 * CC_NPIXP + (t / 3) * CC_PWH + (t % 3)) * 8; };
-            h16x8 xf[2][4];
+        // One k step s of a chunk = (tap t = s / UPT, u = s % UPT): four fragment reads (one per token tile) + eight MFMAs.  The reads of
+        // step s + 1 are issued in FRONT of step s's MFMAs (they fit under the previous step's last MFMA) -- across chunks too: the barrier
+        // "chunk c + 1 has landed" is met at the START of chunk c's last step (every read of chunk c has returned by then: its buffer
+        // is free for the loaders, who refill the one BEHIND it), and the next chunk's first fragments are fetched under that step's
+        // MFMAs.  The refill of a weight-ring position follows the four MFMAs that consumed it.  One scheduling region per k step; the
+        // body covers one chunk when a chunk is an even number of steps, two when odd (static fragment double-buffer parity).
+        constexpr int CPB = (SPC & 1) ? 2 : 1;
+        int bufo = 0;                                        // the current chunk's patch buffer (halfs)
+        h16x8 xf[2][4];
+        auto frag = [&](int s_, int mt) __attribute__((always_inline)) {       // (lbase[][] points into the CURRENT buffer)
+            const int t = s_ / UPT, u = s_ - t * UPT;
+            return l2d_ld8(smem + lbase[t % 3][u] + (t / 3 + 2 * mt) * (CC_PWH * 64));
+        };
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) xf[0][mt] = l2d_ld8(pb + xoff(0) + mt * (2 * CC_PWH * 8));
+        for (int mt = 0; mt < 4; ++mt) xf[0][mt] = frag(0, mt);
+#ifdef L2D_PROBES
+        int cdone = 0;
+#endif
+        auto body = [&](auto ncc) __attribute__((always_inline)) {
+            constexpr int NC = decltype(ncc)::value;
 #pragma unroll
-            for (int s = 0; s < SPC; ++s) {
-                if (s + 1 < SPC) {
+            for (int j = 0; j < NC; ++j) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) xf[(s + 1) & 1][mt] = l2d_ld8(pb + xoff(s + 1) + mt * (2 * CC_PWH * 8));
+                for (int s = 0; s < SPC; ++s) {
+                    const int gs = j * SPC + s;
+                    if (s + 1 == SPC) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this chunk has returned
+#ifdef L2D_PROBES
+                        if (wave == 0 && cdone < 8) CC_STAMP(16 + cdone);    // chunk done (all but its last step's MFMAs)
+                        ++cdone;
+#endif
+                        __builtin_amdgcn_s_barrier();            // this chunk's buffer is free; the next chunk has landed
+                        asm volatile("" ::: "memory");
+                        const int delta = bufo == (CC_NBUF - 1) * CC_PBUFH ? -(CC_NBUF - 1) * CC_PBUFH : CC_PBUFH;      // wave-uniform
+                        bufo += delta;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                            for (int u = 0; u < UPT; ++u) lbase[dx][u] += delta;
+                    }
+                    // (behind the slice's last chunk these read a buffer nobody filled: never used)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) xf[(gs + 1) & 1][mt] = frag(s + 1 == SPC ? 0 : s + 1, mt);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[gs % R][i], xf[gs & 1][mt], acc[i][mt], 0, 0, 0);
+                        if (i == 0) asm volatile("" : "+s"(wcur));
+                        wr[gs % R][i] = cc_wload(wp + (wcur + i * 512) + wlane);   // (beyond the slice: the next slice's / the pad's bytes, never used)
+                    }
+                    wcur += 1024;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % R][i], xf[s & 1][mt], acc[i][mt], 0, 0, 0);
-                    if (i == 0) asm volatile("" : "+s"(wcur));
-                    wr[s % R][i] = l2d_ld8(wp + (wcur + i * 512) + wlane);   // (beyond the slice: the next slice's / the pad's bytes, never used)
-                }
-                wcur += 1024;
-                __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this chunk has returned
-            if (wave == 0 && c < 8) CC_STAMP(16 + c);        // chunk c done (issue side)
-            __builtin_amdgcn_s_barrier();                    // done with chunk c's buffer; chunk c + 1 has landed
-            asm volatile("" ::: "memory");
+        };
+        int c = 0;
+        for (; c + CPB <= n; c += CPB) body(std::integral_constant<int, CPB>{});
+        if constexpr (CPB == 2) {
+            if (c < n) body(std::integral_constant<int, 1>{});
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the trailing prefetch)
         if (wave == 0) CC_STAMP(3);
     }
 
@@ -245,24 +329,24 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
     f32x16 own[2][OWN];
     float *red = reinterpret_cast<float *>(smem);
     constexpr int NPARK = 4 - OWN;                           // parked tiles per wave
+    // parked tile mt of the wave of K group k is that wave's j-th parked tile: j = mt - #(tiles below mt that k owns)
+    auto park_idx = [](int mt, int k) { int own_below = 0; for (int m = k; m < mt; m += KG) ++own_below; return mt - own_below; };
     if constexpr (KG > 1) {
         if (cons) {
             auto park = [&](auto kc) {
                 constexpr int K_ = decltype(kc)::value;
-                int j = 0;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     if (mt % KG == K_) continue;
+                    const int blk = ((cgw * KG + K_) * NPARK + park_idx(mt, K_)) * 2;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) {
                             const f32x4 v = {acc[i][mt][4 * e4], acc[i][mt][4 * e4 + 1], acc[i][mt][4 * e4 + 2], acc[i][mt][4 * e4 + 3]};
-                            *reinterpret_cast<f32x4 *>(red + ((((cgw * KG + K_) * 4 + mt) * 2 + i) * 4 + e4) * 256 + lane * 4) = v;
+                            *reinterpret_cast<f32x4 *>(red + ((blk + i) * 4 + e4) * 256 + lane * 4) = v;
                         }
-                    ++j;
                 }
-                (void)j;
             };
             if (kgw == 0) park(std::integral_constant<int, 0>{});
             else if (kgw == 1) park(std::integral_constant<int, 1>{});
@@ -275,8 +359,6 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                 constexpr int K_ = decltype(kc)::value;
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int mt = K_ + KG * m;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -286,9 +368,10 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                             f32x16 p;
                             if (k == K_) p = acc[i][mt];
                             else {
+                                const int blk = ((cgw * KG + k) * NPARK + park_idx(mt, k)) * 2;
 #pragma unroll
                                 for (int e4 = 0; e4 < 4; ++e4) {
-                                    const f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((((cgw * KG + k) * 4 + mt) * 2 + i) * 4 + e4) * 256 + lane * 4);
+                                    const f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((blk + i) * 4 + e4) * 256 + lane * 4);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) p[4 * e4 + e] = v[e];
                                 }
@@ -313,17 +396,25 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
 #pragma unroll
             for (int m = 0; m < OWN; ++m) own[i][m] = acc[i][m];
     }
-    (void)NPARK;
 
     const int tile = tile_n * a.npat + pat;
-    unsigned int *flag = reinterpret_cast<unsigned int *>(smem + 128 * (BN + 8));    // behind the staged tile
+    float *par = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + CC_PAR_OFF);      // bias [BN] | time-embedding row [BN]
+    unsigned int *flag = reinterpret_cast<unsigned int *>(par + 2 * BN);
     if (a.S > 1) {
-        // split-K, reduction fused (protocol of igemm.hip / wsgemm.hip): partial tiles leave as write-through (sc1) stores into the
-        // tile's slab, lane-linear; the block that arrives last sums the S slabs in the fixed order 0..S-1 and runs the epilogue
+        // Split-K, reduction fused, no fences (igemm.hip explains why), and the reducing block neither publishes nor re-reads its own
+        // partial tile: a block first draws a TICKET; the S - 1 blocks that do not draw the last one park their partial tiles in the
+        // tile's slab with write-through (sc1) stores, drain them, and count themselves DONE; the block with the last ticket -- every
+        // other slice of its tile is by then inside its epilogue, i.e. resident and past its last dependence on anything, so waiting
+        // for them cannot deadlock whatever else shares the GPU -- polls DONE (one lane, relaxed, sleeping), then sums the slabs in the
+        // fixed order 0..S-1 with its own registers at its own position: bit-repeatable whoever reduces.  It leaves both counters zero.
         constexpr int AUX_SC1 = 16;
         constexpr int SLABF = 128 * BN;
         float *slab = a.ws + (long long)tile * a.S * SLABF;
+        unsigned int *tk = a.cnt + 2 * tile;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.S * SLABF * 4, 0x00020000);
+        // every block starts parking its partial tile at once -- the stores are asynchronous and the ticket's round trip runs beside them;
+        // the block that turns out to hold the last ticket simply does not wait for them (its slab is never read)
+        if (tid == 0) *flag = atomicAdd(tk, 1u);
         if (cons) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -336,36 +427,69 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                                                                (z * SLABF + ((((wave * 2 + i) * OWN + m) * 4 + e4) * 256)) * 4 + lane * 16, 0, AUX_SC1);
                     }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's partials have been written through ...
-        __syncthreads();                                        // ... every thread's have
-        if (tid == 0) *flag = atomicAdd(a.cnt + tile, 1u);
         __syncthreads();
         const bool last = (*flag == (unsigned int)(a.S - 1));
+        if (!last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this thread's partials have been written through ...
+            __syncthreads();                                    // ... every thread's have
+            if (tid == 0) atomicAdd(tk + 1, 1u);
+            if (wave == 0) CC_STAMP(5);
+            return;
+        }
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned int)(a.S - 1) && ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(4);
+            atomicExch(tk, 0u);                                 // ready for the next launch that uses these counters
+            atomicExch(tk + 1, 0u);
+        }
+        __syncthreads();
         if (wave == 0) CC_STAMP(5);
-        if (!last) return;
-        if (tid == 0) atomicExch(a.cnt + tile, 0u);             // ready for the next launch that uses this counter
         if (cons) {
+            // the other slices' slabs, ZB at a time (one round trip per batch, not per slab), summed in slice order with this block's
+            // registers at position z
+            constexpr int ZB = KG == 4 ? 4 : 2;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                f32x16 tot[OWN];
 #pragma unroll
                 for (int m = 0; m < OWN; ++m)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) own[i][m][e] = 0.f;
-            for (int zz = 0; zz < a.S; ++zz) {
+                    for (int e = 0; e < 16; ++e) tot[m][e] = 0.f;
+                for (int z0 = 0; z0 < a.S; z0 += ZB) {
+                    f32x4 v[ZB][OWN][4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int b = 0; b < ZB; ++b) {
+                        const int zz = z0 + b;
+                        const int zr = (zz < a.S && zz != z) ? zz : (z == 0 ? (a.S > 1 ? 1 : 0) : 0);      // (clamped: an unconditional load of a valid slab)
 #pragma unroll
-                    for (int m = 0; m < OWN; ++m)
+                        for (int m = 0; m < OWN; ++m)
 #pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) {
-                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                rs, (zz * SLABF + ((((wave * 2 + i) * OWN + m) * 4 + e4) * 256)) * 4 + lane * 16, 0, AUX_SC1));
+                            for (int e4 = 0; e4 < 4; ++e4)
+                                v[b][m][e4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, (zr * SLABF + ((((wave * 2 + i) * OWN + m) * 4 + e4) * 256)) * 4 + lane * 16, 0, AUX_SC1));
+                    }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) own[i][m][4 * e4 + e] += v[e];
+                    for (int b = 0; b < ZB; ++b) {
+                        const int zz = z0 + b;
+                        if (zz >= a.S) break;
+                        if (zz == z) {
+#pragma unroll
+                            for (int m = 0; m < OWN; ++m) tot[m] += own[i][m];
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                                for (int e4 = 0; e4 < 4; ++e4)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) tot[m][4 * e4 + e] += v[b][m][e4][e];
                         }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) own[i][m] = tot[m];
             }
         }
-        __syncthreads();
         if (wave == 0) CC_STAMP(6);
     }
 
@@ -384,7 +508,6 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
     }
     constexpr int pitch = BN + 8;
     h16 *ot = smem;
-    const float *rb = a.rowbias ? a.rowbias + (long long)((bb * a.H * a.W) / a.rows_per_bias) * a.ldrb : nullptr;
     if (cons) {
         // D layout of the 32x32 MFMA: lane -> token (l32 of the tile), register r -> channel (r & 3) + 8 (r >> 2) + 4 lh
 #pragma unroll
@@ -393,8 +516,8 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int ch = cgw * 64 + i * 32 + 8 * g4 + 4 * lh;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias) bv = *reinterpret_cast<const f32x4 *>(a.bias + n0 + ch);
-                if (rb) bv += *reinterpret_cast<const f32x4 *>(rb + n0 + ch);
+                if (a.bias) bv = *reinterpret_cast<const f32x4 *>(par + ch);
+                if (a.rowbias) bv += *reinterpret_cast<const f32x4 *>(par + BN + ch);
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     const int mt = kgw + KG * m;
@@ -483,8 +606,7 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
     a.probe = g_cconv_probe;
 #endif
     if (!a.gn1 && a.gn2) { a.gn1 = a.gn2; a.cpg1 = a.cpg2; a.choff1 = a.choff2; a.gn2 = nullptr; }
-    const bool geo = (CG == 2 && KG == 2 && (NLD == 1 || NLD == 2)) || (CG == 1 && KG == 4 && (NLD == 1 || NLD == 2)) ||
-                     (CG == 4 && KG == 1 && NLD == 1);
+    const bool geo = ((CG == 2 && KG == 2) || (CG == 1 && KG == 4)) && (NLD == 1 || NLD == 2 || NLD == 4);
     if (!a.x1 || !a.w || !a.out || !a.zero || !geo || a.B <= 0 || a.H <= 0 || a.W <= 0 || (a.H % CC_PH) || (a.W % CC_PW) ||
         (a.ups && ((a.H | a.W) & 1)) || a.C1 <= 0 || (a.C1 % 64) || a.C2 < 0 || (a.C2 % 64) || (a.C2 > 0 && !a.x2) || CinP != a.C1 + a.C2 ||
         a.Nout <= 0 || (a.Nout % (64 * CG)) || (a.ldx1 % 8) || a.ldx1 < a.C1 || (a.C2 > 0 && ((a.ldx2 % 8) || a.ldx2 < a.C2)) ||
@@ -515,18 +637,13 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     a.nwg = (int)nwg;
-    const int NCW = CG * KG, BN = 64 * CG;
-    const size_t patch = (size_t)2 * CC_PBUFH * 2;
-    const size_t park = KG > 1 ? (size_t)NCW * 4 * 2 * 4 * 256 * 4 : 0;
-    const size_t stage = (size_t)128 * (BN + 8) * 2 + 64;
-    const size_t gnred = (size_t)(NCW * 64 * 8 + BN) * 4;
-    size_t lds = patch;
-    if (park > lds) lds = park;
-    if (stage > lds) lds = stage;
-    if (gnred > lds) lds = gnred;
+    // LDS: three patch buffers, reused by the K groups' parked partials, the staged tile and the GroupNorm reduction; parameters + flag behind
+    const size_t lds = (size_t)CC_PAR_OFF + 2 * 64 * 4 * 4 + 64;
     L2D_DRY_RETURN();
-    if (CG == 2 && KG == 2) { if (NLD == 1) launch_cc<2, 2, 1>(a, lds, s); else launch_cc<2, 2, 2>(a, lds, s); }
-    else if (CG == 1 && KG == 4) { if (NLD == 1) launch_cc<1, 4, 1>(a, lds, s); else launch_cc<1, 4, 2>(a, lds, s); }
-    else launch_cc<4, 1, 1>(a, lds, s);
+#define CC_LAUNCH(cg, kg) do { if (NLD == 1) launch_cc<cg, kg, 1>(a, lds, s); else if (NLD == 2) launch_cc<cg, kg, 2>(a, lds, s); \
+                               else launch_cc<cg, kg, 4>(a, lds, s); } while (0)
+    if (CG == 2) CC_LAUNCH(2, 2);
+    else CC_LAUNCH(1, 4);
+#undef CC_LAUNCH
     return l2d_check_launch("cconv", op->tag);
 }

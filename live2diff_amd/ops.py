@@ -689,7 +689,7 @@ def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int, KG: Optional[in
             return cg, kg, nld, max(1, min(S, nch))
     npat = B * (H // 8) * (W // 16)
     best = None
-    for cg, kg, nld in ((2, 2, 2), (1, 4, 2)):
+    for cg, kg, nld in ((1, 4, 4), (2, 2, 4)):
         if Nout % (64 * cg) or (KG is not None and kg != KG):
             continue
         tiles = npat * (Nout // (64 * cg))
@@ -697,11 +697,14 @@ def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int, KG: Optional[in
             blocks = tiles * S
             if blocks > 256 and S > 1:
                 break
+            # shader cycles (tools/cconv_stamps.py): a chunk is 3.1 k (KG = 4: 72 MFMAs per wave) / 6.2 k (KG = 2: 144) cycles, a block
+            # pays ~12 k for prologue + K-group reduction + epilogue, a split adds the ticket / publish overlap and one slab read per
+            # other slice; blocks beyond one per CU run as a second round
             chunks = -(-nch // S)
-            loop = chunks * (9 * 4 // kg) * 8 * 32 / (0.72 if kg == 2 else 0.45)
-            tail = ((S - 1) * (2300 if cg == 2 else 1200) + 6000) if S > 1 else 0
+            loop = chunks * (3100 if kg == 4 else 6200)
+            tail = ((10000 if cg == 2 else 9000) + (S - 1) * (4500 if cg == 2 else 2500)) if S > 1 else 0
             rounds = -(-blocks // 256)
-            cost = rounds * (loop + 14000 + tail)
+            cost = rounds * (loop + 12000) + tail
             if best is None or cost < best[0]:
                 best = (cost, (cg, kg, nld, S))
     assert best is not None, (B, H, W, Nout, CinP, KG)
@@ -717,13 +720,14 @@ def cconv_wanted(B: int, H: int, W: int, Cin: int, Nout: int, ups: int = 0) -> b
         return False
     if ups:
         return True
-    return Nout >= 640 and B * H * W >= 512
+    return B * H * W >= 512 and (Nout >= 640 or os.environ.get("L2D_CCONV_L0", "1") != "0")
 
 
 def cconv_sizes(B: int, H: int, W: int, Nout: int, CG: int, S: int):
-    """(fp32 workspace elements, int32 counters) of a split-K cconv launch: one 128 x 64 CG slab per (tile, slice)"""
+    """(fp32 workspace elements, int32 counters) of a split-K cconv launch: one 128 x 64 CG slab per (tile, slice), a ticket and a
+    done counter per tile"""
     tiles = B * (H // 8) * (W // 16) * (Nout // (64 * CG))
-    return tiles * S * 128 * 64 * CG, tiles
+    return tiles * S * 128 * 64 * CG, 2 * tiles
 
 
 def cconv(x1, w, out, *, B, H, W, C1, ldx1, Nout, ldo, KG, x2=None, C2=0, ldx2=0, ups=0, bias=None, rowbias=None, ldrb=0,

@@ -45,7 +45,10 @@ def _bufs(L, B, H, W, N, CG, S):
     (2, 16, 16, 1280, 0, 1280, (1, 4, 1, 5)),
     (2, 16, 16, 1280, 0, 1280, (2, 2, 1, 6)),     # ragged slices: 20 chunks over 6
     (2, 64, 64, 320, 0, 320, (1, 4, 2, 1)),       # level 0
-    (2, 16, 16, 256, 0, 256, (4, 1, 1, 2)),       # one 256-channel tile, no K groups
+    (2, 16, 16, 256, 0, 256, (2, 2, 4, 2)),       # four loader waves
+    (2, 16, 16, 1280, 0, 1280, (1, 4, 4, 3)),
+    (2, 32, 32, 64, 0, 128, (2, 2, 4, 1)),        # one chunk: the loaders' short path
+    (2, 32, 32, 128, 0, 128, (1, 4, 2, 1)),       # two chunks
     (1, 8, 16, 64, 0, 64, (1, 4, 1, 1)),          # one patch: every pixel is a border pixel somewhere
     (3, 8, 16, 64, 64, 128, (2, 2, 1, 2)),
     (8, 16, 16, 128, 0, 128, (2, 2, 2, 1)),       # warm-up style batch

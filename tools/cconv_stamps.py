@@ -18,8 +18,9 @@ CASES = [  # name, B, H, W, Cin, Cout, ups, sched
     ("L1 640->640 S1", 2, 32, 32, 640, 640, 0, (2, 2, 2, 1)),
     ("L1 1920->640", 2, 32, 32, 1920, 640, 0, (2, 2, 2, 3)),
     ("L2 1280->1280", 2, 16, 16, 1280, 1280, 0, (2, 2, 2, 6)),
-    ("L2 1280->1280 KG4", 2, 16, 16, 1280, 1280, 0, (1, 4, 2, 3)),
-    ("L0 320->320", 2, 64, 64, 320, 320, 0, (1, 4, 2, 1)),
+    ("L2 1280->1280 KG4", 2, 16, 16, 1280, 1280, 0, (1, 4, 4, 3)),
+    ("L1 640->640 KG4 S1", 2, 32, 32, 640, 640, 0, (1, 4, 4, 1)),
+    ("L0 320->320", 2, 64, 64, 320, 320, 0, (1, 4, 4, 1)),
     ("UP2", 2, 32, 32, 1280, 1280, 1, (2, 2, 2, 1)),
 ]
 NAMES = {0: "entry", 1: "ring requested", 2: "chunk 0 landed", 3: "loop done", 4: "K groups met", 5: "slab out + arrival", 6: "slabs summed",
@@ -50,7 +51,7 @@ def main():
         out = torch.empty(M, Cout, dtype=torch.float16, device=DEV)
         n_ws, n_cnt = L.cconv_sizes(B, H, W, Cout, CG, S)
         ws = torch.empty(max(1, n_ws), dtype=torch.float32, device=DEV) if S > 1 else None
-        nblk = (n_cnt if True else 0) * S
+        nblk = (n_cnt // 2) * S
         probe = torch.zeros(nblk * 32, dtype=torch.int64, device=DEV)
         pl = _lib.OpList()
         for k in range(R):
@@ -81,7 +82,7 @@ def main():
             return float("nan") if v.numel() == 0 else float(v.median())
         print("   compute: " + "  ".join(f"{NAMES[i]} {med(i):.0f}" for i in (1, 2, 3, 4, 5, 6, 7, 8)))
         print("   chunk done: " + " ".join(f"{med(16 + c):.0f}" for c in range(8)))
-        print("   loader:  " + "  ".join(f"{NAMES[i]} {med(i):.0f}" for i in (10, 11, 12, 13)) + "   chunk c+1 landed: " + " ".join(f"{med(24 + c):.0f}" for c in range(6)))
+        print("   loader:  " + "  ".join(f"{NAMES[i]} {med(i):.0f}" for i in (10, 11, 12, 13)) + "   chunk c+1 landed: " + " ".join(f"{med(24 + c):.0f}" for c in range(6)) + "   chunk c+2 issued (c=1..3): " + " ".join(f"{med(13 + c):.0f}" for c in (1, 2, 3)))
         last = p[:, 6] > 0
         if S > 1 and last.any():
             r2 = rel[last]

@@ -116,14 +116,14 @@ def main():
             cands = [tuple(int(v) for v in s.split(",")) for s in a.scheds.split(";")]
         else:
             cands = []
-            for cg, kg in ((2, 2), (1, 4), (4, 1)):
+            for cg, kg in ((2, 2), (1, 4)):
                 if Cout % (64 * cg):
                     continue
                 tiles = npat * Cout // (64 * cg)
                 for S in (1, 2, 3, 4, 5, 6, 8):
                     if S > nch or (S > 1 and tiles * S > 330) or (S == 1 and tiles < 100 and nch > 4):
                         continue
-                    for nld in ((1, 2) if cg != 4 else (1,)):
+                    for nld in (2, 4):
                         cands.append((cg, kg, nld, S))
         packed = {}
         for sched in cands:
