@@ -714,13 +714,14 @@ def cconv_schedule(B: int, H: int, W: int, Nout: int, CinP: int, KG: Optional[in
 def cconv_wanted(B: int, H: int, W: int, Cin: int, Nout: int, ups: int = 0) -> bool:
     """Whether the plan gives a 3x3 stride-1 conv to cconv.hip (H x W = output resolution).  Measured at cfg-2 against the kernel
     each launch had before (tools/cconv_time.py, profiles/round6_a_cconv_time.log): the up-samplers 1.4-1.5 x (igemm), the resnet
-    convs of the 640- / 1280-wide levels 1.0-1.35 x (wsgemm); the 320-wide level keeps the patch conv (0.87 x: 320 blocks of one
-    64-channel tile are two rounds over the chip).  L2D_CCONV=0 switches the kernel off (A/B)."""
+    convs of the 640- / 1280-wide levels 1.2-1.6 x (wsgemm); the 320-wide level keeps the patch conv by default (1.02-1.14 x in isolation,
+    nothing in the frame: 320 blocks of one 64-channel tile are two rounds over the chip; L2D_CCONV_L0=1 moves it too).  L2D_CCONV=0
+    switches the kernel off (A/B)."""
     if os.environ.get("L2D_CCONV", "1") == "0" or not cconv_ok(H, W, Nout, Cin):
         return False
     if ups:
         return True
-    return B * H * W >= 512 and (Nout >= 640 or os.environ.get("L2D_CCONV_L0", "1") != "0")
+    return B * H * W >= 512 and (Nout >= 640 or os.environ.get("L2D_CCONV_L0", "0") != "0")
 
 
 def cconv_sizes(B: int, H: int, W: int, Nout: int, CG: int, S: int):
