@@ -63,6 +63,11 @@ struct CConvArgs {
     int Nout, ldo, ldr, ldrb, rows_per_bias;
     int npx, npy, npat, ntn, S, cps, crem, nwg;
     int gnT, gnG, cpg1, choff1, cpg2, choff2;
+    // GroupNorm (+ SiLU) of the INPUT fused into the loaders (pro = 1): statistics of the input from its producers' fixed-point atomics
+    const long long *pacc;         // int64 [B][pG][2]: sum x in units of 2^-20, sum x^2 in units of 2^-12 (as L2D_OP_GN_APPLY with nchunk = 0)
+    const h16 *pgamma, *pbeta;     // [C1 + C2]
+    int pro, pG;
+    float peps;
 #ifdef L2D_PROBES
     unsigned long long *probe;     // analysis builds: 32 s_memtime stamps per block (tools/cconv_stamps.py)
 #endif
@@ -81,6 +86,8 @@ constexpr int CC_PH = 8, CC_PW = 16, CC_PWH = CC_PW + 2, CC_NPIX = (CC_PH + 2) *
 constexpr int CC_PBUFH = CC_NPIXP * 64;             // halfs per patch buffer: 192 pixels x 64 channels = 24 KB
 constexpr int CC_RING = 9;                          // weight ring depth in k steps (2 KB each)
 constexpr int CC_NBUF = 3;                          // patch buffers: the loaders run two chunks ahead of the compute waves
+constexpr int CC_TBL_OFF = CC_NBUF * 24576;          // byte offset of the fused-GroupNorm (scale | shift) tables: one 512-byte entry per chunk of the slice
+constexpr int CC_TBL_MAXCH = 48;                    // ... at most this many chunks per K slice when the input GroupNorm is fused
 constexpr int CC_PAR_OFF = 100 * 1024;              // byte offset of the epilogue parameters (bias | time-embedding row) + flag word in LDS
 }  // namespace
 
@@ -205,24 +212,70 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         // The loaders run TWO chunks ahead (three patch buffers): the DMAs of chunk c + 2 are in flight while chunk c + 1 lands and chunk
         // c is consumed; a loader waits for "all but my DPC youngest" (in-order return), never for an empty queue inside the loop.
         issue_chunk(0, 0);
-        if (n > 1) {
-            issue_chunk(1, CC_PBUFH * 2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n > 1) issue_chunk(1, CC_PBUFH * 2);
+        // Fused input GroupNorm + SiLU (the reference's `conv(F.silu(norm(x)))`, resnet.py:233-234,249-250): the raw activations are DMA'd as
+        // before; once a loader's share of a chunk has landed it normalises those very bytes in place -- y = silu(x scale[c] + shift[c]),
+        // fp32, rounded to fp16 exactly where the separate GroupNorm launch rounded -- before the chunk is handed to the compute waves.
+        // Pixels outside the image stay zero (the conv pads the NORMALISED tensor).  scale = rstd gamma, shift = beta - mean rstd gamma per
+        // channel of this block's sample come from the producers' fixed-point sums; the tables of the slice's chunks are built once, here,
+        // under the first DMAs (chunk c by loader c mod NLD, lane = channel).
+        float *tbl = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + CC_TBL_OFF);
+        if (a.pro) {
+            const int cpg = (a.C1 + a.C2) / a.pG;
+            const float inv = 1.0f / ((float)(a.Hs * a.Ws) * (float)cpg);
+            for (int c = l; c < n; c += NLD) {
+                const int ch = (c0 + c) * 64 + lane;
+                const long long *src = a.pacc + ((long long)bb * a.pG + ch / cpg) * 2;
+                const float sm = (float)((double)src[0] * (1.0 / 1048576.0));
+                const float sq = (float)((double)src[1] * (1.0 / 4096.0));
+                const float mean = sm * inv;
+                const float var = fmaxf(sq * inv - mean * mean, 0.f);
+                const float sc = rsqrtf(var + a.peps) * (float)a.pgamma[ch];
+                tbl[c * 128 + lane] = sc;
+                tbl[c * 128 + 64 + lane] = (float)a.pbeta[ch] - mean * sc;
+            }
+        }
+        auto norm_chunk = [&](int c, unsigned bufo) __attribute__((always_inline)) {      // this loader's share of chunk c, in place
+            h16 *base = smem + (bufo >> 1) + l * (DPC * 512) + lane * 8;
+            const float *tc = tbl + c * 128;
+#pragma unroll
+            for (int jj = 0; jj < DPC; ++jj) {
+                if (!okp[jj]) continue;                       // (outside the image / beyond the patch: zeros stay zeros)
+                const int q8 = (int)(qb[jj] >> 1);            // first channel of this lane's 16-byte slot
+                h16x8 v = l2d_ld8(base + jj * 512);
+                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(tc + q8), s1 = *reinterpret_cast<const f32x4 *>(tc + q8 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(tc + 64 + q8), h1 = *reinterpret_cast<const f32x4 *>(tc + 64 + q8 + 4);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (h16)l2d_silu((float)v[e] * s0[e] + h0[e]);
+                    o[4 + e] = (h16)l2d_silu((float)v[4 + e] * s1[e] + h1[e]);
+                }
+                l2d_st8(base + jj * 512, o);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        if (n > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.pro) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // (pro only, loaders AND compute waves: every loader's tables are written)
+            asm volatile("" ::: "memory");
+            norm_chunk(0, 0);
         }
         if (l == 0) CC_STAMP(12);
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
-        unsigned bufn = 2 * CC_PBUFH * 2;                     // buffer of chunk c + 2
+        unsigned bufn = 2 * CC_PBUFH * 2, buf1 = CC_PBUFH * 2;   // buffers of chunk c + 2 / chunk c + 1
         for (int c = 0; c < n; ++c) {
             if (c + 2 < n) {
                 issue_chunk(c + 2, bufn);                    // (its buffer was chunk c - 1's: every wave passed the previous barrier)
                 bufn = bufn == (CC_NBUF - 1) * CC_PBUFH * 2 ? 0u : bufn + CC_PBUFH * 2;
-                if (l == 0 && c >= 1 && c < 4) CC_STAMP(13 + c);         // chunk c + 2 issued (stamps 14..16)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPC) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (a.pro && c + 1 < n) norm_chunk(c + 1, buf1);
+            buf1 = buf1 == (CC_NBUF - 1) * CC_PBUFH * 2 ? 0u : buf1 + CC_PBUFH * 2;
             if (l == 0 && c < 6) CC_STAMP(24 + c);           // chunk c + 1 landed (this loader's share)
             __builtin_amdgcn_s_barrier();                    // chunk c + 1 has landed; the compute waves are done with chunk c
         }
@@ -254,6 +307,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
                 lbase[dx][u] = (trow * CC_PWH + tcol + dx) * 64 + (((2 * (u * KG + kgw) + lh) ^ (((tcol + dx) >> 1) & 7)) * 8);
         if (wave == 0) CC_STAMP(1);
         asm volatile("" ::: "memory");
+        if (a.pro) __builtin_amdgcn_s_barrier();             // (the loaders' GroupNorm tables are complete: their barrier, met by every wave)
         __builtin_amdgcn_s_barrier();                        // chunk 0 has landed
         asm volatile("" ::: "memory");
         if (wave == 0) CC_STAMP(2);
@@ -602,6 +656,8 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
     a.ups = op->i[13] ? 1 : 0;
     a.Nout = op->i[14]; a.ldo = op->i[15]; a.ldr = op->i[16]; a.ldrb = op->i[17]; a.rows_per_bias = op->i[18];
     a.gnT = op->i[24]; a.gnG = op->i[25]; a.cpg1 = op->i[26]; a.choff1 = op->i[27]; a.cpg2 = op->i[28]; a.choff2 = op->i[29];
+    a.pacc = (const long long *)op->p[13]; a.pgamma = (const h16 *)op->p[14]; a.pbeta = (const h16 *)op->p[15];
+    a.pro = op->i[20]; a.pG = op->i[21]; a.peps = op->f[0];
 #ifdef L2D_PROBES
     a.probe = g_cconv_probe;
 #endif
@@ -611,7 +667,9 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
         (a.ups && ((a.H | a.W) & 1)) || a.C1 <= 0 || (a.C1 % 64) || a.C2 < 0 || (a.C2 % 64) || (a.C2 > 0 && !a.x2) || CinP != a.C1 + a.C2 ||
         a.Nout <= 0 || (a.Nout % (64 * CG)) || (a.ldx1 % 8) || a.ldx1 < a.C1 || (a.C2 > 0 && ((a.ldx2 % 8) || a.ldx2 < a.C2)) ||
         (a.ldo % 8) || a.ldo < a.Nout || (a.res && ((a.ldr % 8) || a.ldr < a.Nout)) || (a.rowbias && (a.ldrb <= 0 || a.rows_per_bias <= 0)) ||
-        a.S > CinP / 64 || (a.S > 1 && (!a.ws || !a.cnt)) ||
+        a.S > CinP / 64 || (a.S > 1 && (!a.ws || !a.cnt)) || a.pro < 0 || a.pro > 1 ||
+        (a.pro && (!a.pacc || !a.pgamma || !a.pbeta || a.ups || a.pG <= 0 || (CinP % a.pG) || !(a.peps > 0.f) ||
+                   (CinP / 64 + a.S - 1) / a.S > CC_TBL_MAXCH || (((unsigned long long)a.pacc | (unsigned long long)a.pgamma | (unsigned long long)a.pbeta) & 7))) ||
         (((unsigned long long)a.x1 | (unsigned long long)a.x2 | (unsigned long long)a.w | (unsigned long long)a.out |
           (unsigned long long)a.res | (unsigned long long)a.bias | (unsigned long long)a.rowbias | (unsigned long long)a.ws |
           (unsigned long long)a.zero) & 15)) {

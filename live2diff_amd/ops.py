@@ -732,11 +732,14 @@ def cconv_sizes(B: int, H: int, W: int, Nout: int, CG: int, S: int):
 
 
 def cconv(x1, w, out, *, B, H, W, C1, ldx1, Nout, ldo, KG, x2=None, C2=0, ldx2=0, ups=0, bias=None, rowbias=None, ldrb=0,
-          rows_per_bias=0, res=None, ldr=0, sched=None, ws=None, cnt=None, cnt_off=0):
+          rows_per_bias=0, res=None, ldr=0, sched=None, ws=None, cnt=None, cnt_off=0, gn_acc_ptr=None, gn_gamma=None, gn_beta=None,
+          gn_G=0, gn_eps=1e-5):
     """3x3 stride-1 pad-1 conv with the activation patch resident in LDS and register-streamed weights (csrc/cconv.hip).
     H x W = OUTPUT resolution; ups = 1: the input is [B, H/2, W/2, C] and is up-sampled x2 (nearest) on the fly (Upsample3D).
     `w` = pack_cconv(weight, KG).  sched = (CG, KG, NLD, S) or None for cconv_schedule (its KG must equal the packing's);
-    S > 1 needs `ws` / `cnt` (cconv_sizes)."""
+    S > 1 needs `ws` / `cnt` (cconv_sizes).  gn_acc_ptr (+ gn_gamma / gn_beta fp16 [C1 + C2], gn_G, gn_eps): the conv of
+    silu(GroupNorm(x)) -- the normalisation runs in the kernel's loader waves from the producers' fixed-point statistics
+    (int64 [B][G][2], as gn_apply with nchunk = 0): no GroupNorm launch, no normalised tensor in HBM."""
     op = L2dOp()
     op.kind = _lib.OP_CCONV
     CinP = C1 + C2
@@ -759,9 +762,14 @@ def cconv(x1, w, out, *, B, H, W, C1, ldx1, Nout, ldo, KG, x2=None, C2=0, ldx2=0
         op.p[12] = _ptr(ws)
     vals = {1: C1, 2: C2, 3: ldx1, 4: ldx2, 5: CinP, 6: B, 7: H, 8: W, 9: CG, 10: KG, 11: NLD, 12: S, 13: ups, 14: Nout, 15: ldo,
             16: ldr, 17: ldrb, 18: rows_per_bias}
+    if gn_acc_ptr is not None:
+        assert gn_gamma.dtype == torch.float16 and gn_beta.dtype == torch.float16 and gn_gamma.numel() == CinP and gn_beta.numel() == CinP
+        op.p[13], op.p[14], op.p[15] = int(gn_acc_ptr), _ptr(gn_gamma), _ptr(gn_beta)
+        vals.update({20: 1, 21: gn_G})
+        op.f[0] = float(gn_eps)
     for j, v in vals.items():
         op.i[j] = int(v)
-    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt)
+    return op, (x1, x2, w, bias, rowbias, res, out, zp, ws, cnt, gn_gamma, gn_beta)
 
 
 def cconv_gn_target(op, acc_ptr: int, *, T: int, G: int, cpg: int, choff: int) -> bool:

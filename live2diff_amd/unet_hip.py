@@ -632,15 +632,18 @@ class HipStreamingUNet:
             ar.release(partial)
             return out
 
-        def conv3(x: _Act, name, stride=1, ups=0, epi=0, res: Optional[_Act] = None, rowbias=None) -> _Act:
+        def conv3(x: _Act, name, stride=1, ups=0, epi=0, res: Optional[_Act] = None, rowbias=None, x2: Optional[_Act] = None,
+                  gnf=None) -> _Act:
+            """x2 / gnf = (acc_ptr, gamma, beta, eps): cconv only -- the conv of silu(GroupNorm(x | x2)), normalised inside the launch"""
             if (name + ".cw") in W:
                 # patch-resident activations + register-streamed weights (cconv.hip): resnet convs of the wide levels, up-samplers
                 assert stride == 1 and epi == 0
                 cout = W[name + ".b"].numel()
                 Ho, Wo = x.H << ups, x.W << ups
                 out = new_act(cout, Ho, Wo)
-                kg = ops.cconv_schedule(self.N, Ho, Wo, cout, x.C)[1]          # (the packing's: decided on the stream batch)
-                sched = ops.cconv_schedule(B, Ho, Wo, cout, x.C, KG=kg)
+                cin = x.C + (x2.C if x2 is not None else 0)
+                kg = ops.cconv_schedule(self.N, Ho, Wo, cout, cin)[1]          # (the packing's: decided on the stream batch)
+                sched = ops.cconv_schedule(B, Ho, Wo, cout, cin, KG=kg)
                 ws_buf, kw = None, {}
                 if sched[3] > 1:
                     n_ws, n_cnt = ops.cconv_sizes(B, Ho, Wo, cout, sched[0], sched[3])
@@ -649,6 +652,10 @@ class HipStreamingUNet:
                     st.sk_used += n_cnt
                 if rowbias is not None:
                     kw.update(rowbias=st.temb_all, ldrb=self.temb_total, rows_per_bias=(Ho * Wo if mode == "stream" else B * Ho * Wo))
+                if gnf is not None:
+                    kw.update(gn_acc_ptr=gnf[0], gn_gamma=gnf[1], gn_beta=gnf[2], gn_G=G, gn_eps=gnf[3])
+                if x2 is not None:
+                    kw.update(x2=x2.buf, C2=x2.C, ldx2=x2.C)
                 op_ = add(ops.cconv(x.buf, W[name + ".cw"], out.buf, B=B, H=Ho, W=Wo, C1=x.C, ldx1=x.C, Nout=cout, ldo=cout, KG=kg, ups=ups,
                                     bias=W[name + ".b"], res=(res.buf if res is not None else None), ldr=(res.C if res is not None else 0),
                                     sched=sched, **kw))
@@ -657,6 +664,7 @@ class HipStreamingUNet:
                 ar.release(ws_buf)
                 out.producer = op_
                 return out
+            assert x2 is None and gnf is None
             if use_ws(name):
                 # resnet conv at a few-token level: weight-streaming GEMM over (tap, channel chunk) stages (wsgemm.hip)
                 assert stride == 1 and not ups and epi == 0
@@ -855,20 +863,33 @@ class HipStreamingUNet:
                                   eps_gn=cfg.transformer_norm_eps, eps_ln=1e-5, out_t=out_t, ldt=ldt, st=stt, ldo=ldo))
             return h
 
-        def resnet(x: _Act, name, skip: Optional[_Act] = None) -> _Act:
-            hn = gn(x, name + ".norm1", cfg.norm_eps, True, x2=skip)
-            h1 = conv3(hn, name + ".conv1", rowbias=self.temb_offsets[name])
+        gn_in_conv = os.environ.get("L2D_CCONV_GN", "1") != "0"        # A/B knob: 0 = a GroupNorm launch in front of every conv
+
+        def gn_conv3(x: _Act, x2: Optional[_Act], nname, cname, **kw) -> _Act:
+            """conv3(silu(GroupNorm(x | x2))) (reference resnet.py:233-234, 249-250).  Where the conv is a cconv launch and the statistics
+            come from the producers' epilogues, the normalisation runs inside that launch (its loader waves normalise the patch in LDS):
+            no GroupNorm launch, no normalised tensor; else GroupNorm launch + conv."""
+            if gn_in_conv and (cname + ".cw") in W:
+                C_ = x.C + (x2.C if x2 is not None else 0)
+                if C_ % G == 0 and -(-(C_ // 64) // 1) <= 8 * 48:
+                    acc_ptr = gn_stats_target(x, x2, x.H * x.W, C_ // G)
+                    if acc_ptr is not None:
+                        return conv3(x, cname, x2=x2, gnf=(acc_ptr, W[nname + ".g"], W[nname + ".beta"], cfg.norm_eps), **kw)
+            hn = gn(x, nname, cfg.norm_eps, True, x2=x2)
+            out_ = conv3(hn, cname, **kw)
             free(hn)
-            h2 = gn(h1, name + ".norm2", cfg.norm_eps, True)
-            free(h1)
+            return out_
+
+        def resnet(x: _Act, name, skip: Optional[_Act] = None) -> _Act:
+            h1 = gn_conv3(x, skip, name + ".norm1", name + ".conv1", rowbias=self.temb_offsets[name])
             if (name + ".conv_shortcut.w") in W or (name + ".conv_shortcut.ww") in W:
                 sc = linear(x, name + ".conv_shortcut", x2=skip)
-                out = conv3(h2, name + ".conv2", res=sc)
+                out = gn_conv3(h1, None, name + ".norm2", name + ".conv2", res=sc)
                 free(sc)
             else:
                 assert skip is None
-                out = conv3(h2, name + ".conv2", res=x)
-            free(h2)
+                out = gn_conv3(h1, None, name + ".norm2", name + ".conv2", res=x)
+            free(h1)
             return out
 
         def spatial(x: _Act, name) -> _Act:

@@ -172,6 +172,55 @@ def test_cconv_agrees_with_igemm_and_feeds_groupnorm(L):
         assert relerr(y, gref) <= 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,N,G,sched", [
+    (2, 32, 32, 640, 0, 640, 32, (1, 4, 4, 1)),       # level 1 resnet conv behind its GroupNorm
+    (2, 32, 32, 640, 320, 640, 32, (2, 2, 4, 3)),     # concat input (up block): groups straddle nothing, chunks stay inside one input
+    (2, 16, 16, 1280, 0, 1280, 32, (1, 4, 4, 3)),
+    (2, 16, 16, 1280, 1280, 1280, 32, (1, 4, 2, 3)),
+    (3, 8, 16, 64, 0, 64, 4, (1, 4, 1, 1)),           # one patch per sample: every halo pixel is padding
+    (2, 16, 32, 128, 64, 128, 8, (2, 2, 2, 2)),
+])
+def test_cconv_fused_groupnorm_silu(L, B, H, W, C1, C2, N, G, sched):
+    """conv(silu(GroupNorm(x))) (reference resnet.py:233-234, 249-250) as ONE launch: statistics as the producers leave them (fixed-point
+    int64 sums), normalisation in the loader waves, zero padding applied to the NORMALISED tensor.  Against fp32 torch, and against the
+    two-launch path (gn_apply, then cconv) it replaces."""
+    CG, KG, NLD, S = sched
+    C, T, M = C1 + C2, H * W, B * H * W
+    x = rnd(B, H, W, C, seed=41) * 1.5 + rnd(1, 1, 1, C, seed=42)           # per-channel offsets: the mean matters
+    w = rnd(N, C, 3, 3, seed=43, scale=(9 * C) ** -0.5)
+    b = rnd(N, seed=44).float()
+    gm, bt = (1 + 0.2 * rnd(C, seed=45).float()).half(), (0.2 * rnd(C, seed=46).float()).half()
+    eps = 1e-5
+    xn = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), G, gm.float(), bt.float(), eps))
+    ref = F.conv2d(xn.half().float(), w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    # the statistics exactly as a producer's epilogue accumulates them
+    cpg = C // G
+    xs = x.double().view(B, T, G, cpg)
+    acc = torch.stack([(xs.sum((1, 3)) * 2 ** 20).round(), ((xs ** 2).sum((1, 3)) * 2 ** 12).round()], -1).to(torch.int64).to(DEV)
+    xd = x.to(DEV)
+    x1 = xd[..., :C1].contiguous()
+    x2 = xd[..., C1:].contiguous() if C2 else None
+    wp = L.pack_cconv(w.to(DEV), KG)
+    out = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+    ws, cnt = _bufs(L, B, H, W, N, CG, S)
+    L.run(L.cconv(x1, wp, out, B=B, H=H, W=W, C1=C1, ldx1=C1, Nout=N, ldo=N, KG=KG, x2=x2, C2=C2, ldx2=C2, bias=b.to(DEV), sched=sched, ws=ws,
+                  cnt=cnt, cnt_off=3, gn_acc_ptr=acc.data_ptr(), gn_gamma=gm.to(DEV), gn_beta=bt.to(DEV), gn_G=G, gn_eps=eps))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    e = relerr(out, ref)
+    assert e <= 2e-3, f"cconv + GroupNorm {B}x{H}x{W} C{C1}+{C2}->{N} G{G} sched {sched}: rel-L2 {e:.3e}"
+    # the two launches it replaces
+    y = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    L.run(L.gn_apply(x1, None, gm.to(DEV), bt.to(DEV), y, B=B, T=T, C1=C1, ld1=C1, G=G, nchunk=0, eps=eps, silu=True, x2=x2, C2=C2, ld2=C2,
+                     acc_ptr=acc.data_ptr()))
+    out2 = torch.zeros_like(out)
+    if ws is not None:
+        ws.fill_(float("nan"))
+    L.run(L.cconv(y, wp, out2, B=B, H=H, W=W, C1=C, ldx1=C, Nout=N, ldo=N, KG=KG, bias=b.to(DEV), sched=sched, ws=ws, cnt=cnt, cnt_off=3))
+    torch.cuda.synchronize()
+    assert relerr(out, out2) <= 3e-4, relerr(out, out2)
+
+
 def test_cconv_rejects_bad_arguments(L):
     from live2diff_amd import _lib
     x, w = rnd(1, 8, 16, 64).to(DEV), L.pack_cconv(rnd(64, 64, 3, 3).to(DEV), 4)
