@@ -238,20 +238,32 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
         auto norm_chunk = [&](int c, unsigned bufo) __attribute__((always_inline)) {      // this loader's share of chunk c, in place
             h16 *base = smem + (bufo >> 1) + l * (DPC * 512) + lane * 8;
             const float *tc = tbl + c * 128;
+            // all reads first (one LDS latency for the whole share, not one per instruction), branch-free arithmetic, a select keeps the
+            // zeros of pixels outside the image / beyond the patch
+            constexpr int NB = DPC > 6 ? 6 : DPC;             // instructions per batch (register budget)
 #pragma unroll
-            for (int jj = 0; jj < DPC; ++jj) {
-                if (!okp[jj]) continue;                       // (outside the image / beyond the patch: zeros stay zeros)
-                const int q8 = (int)(qb[jj] >> 1);            // first channel of this lane's 16-byte slot
-                h16x8 v = l2d_ld8(base + jj * 512);
-                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(tc + q8), s1 = *reinterpret_cast<const f32x4 *>(tc + q8 + 4);
-                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(tc + 64 + q8), h1 = *reinterpret_cast<const f32x4 *>(tc + 64 + q8 + 4);
-                h16x8 o;
+            for (int j0 = 0; j0 < DPC; j0 += NB) {
+                h16x8 v[NB];
+                f32x4 s0[NB], s1[NB], h0[NB], h1[NB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (h16)l2d_silu((float)v[e] * s0[e] + h0[e]);
-                    o[4 + e] = (h16)l2d_silu((float)v[4 + e] * s1[e] + h1[e]);
+                for (int k = 0; k < NB; ++k) {
+                    const int jj = j0 + k;
+                    const int q8 = (int)(qb[jj] >> 1);        // first channel of this lane's 16-byte slot
+                    v[k] = l2d_ld8(base + jj * 512);
+                    s0[k] = *reinterpret_cast<const f32x4 *>(tc + q8); s1[k] = *reinterpret_cast<const f32x4 *>(tc + q8 + 4);
+                    h0[k] = *reinterpret_cast<const f32x4 *>(tc + 64 + q8); h1[k] = *reinterpret_cast<const f32x4 *>(tc + 64 + q8 + 4);
                 }
-                l2d_st8(base + jj * 512, o);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int jj = j0 + k;
+                    h16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = (h16)l2d_silu((float)v[k][e] * s0[k][e] + h0[k][e]);
+                        o[4 + e] = (h16)l2d_silu((float)v[k][4 + e] * s1[k][e] + h1[k][e]);
+                    }
+                    l2d_st8(base + jj * 512, okp[jj] ? o : v[k]);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };

@@ -863,7 +863,11 @@ class HipStreamingUNet:
                                   eps_gn=cfg.transformer_norm_eps, eps_ln=1e-5, out_t=out_t, ldt=ldt, st=stt, ldo=ldo))
             return h
 
-        gn_in_conv = os.environ.get("L2D_CCONV_GN", "1") != "0"        # A/B knob: 0 = a GroupNorm launch in front of every conv
+        # L2D_CCONV_GN=1: the GroupNorm + SiLU in front of a cconv launch runs inside it (its loader waves normalise the patch in LDS).  Built,
+        # parity-tested (tests/test_gpu_cconv.py) and measured in the frame (round 6, profiles/round6_f_cconv_gn_fused_ab.txt): 20 GroupNorm
+        # launches and their 0.135 ms go, but every output-channel tile of a conv re-normalises its patch (10-20 x redundant arithmetic at
+        # the 640 / 1280-wide levels) and the cconv family pays 0.16 ms for it: 7.96-8.01 vs 7.99-8.00 ms per frame.  Off by default.
+        gn_in_conv = os.environ.get("L2D_CCONV_GN", "0") != "0"
 
         def gn_conv3(x: _Act, x2: Optional[_Act], nname, cname, **kw) -> _Act:
             """conv3(silu(GroupNorm(x | x2))) (reference resnet.py:233-234, 249-250).  Where the conv is a cconv launch and the statistics

@@ -173,8 +173,7 @@ def test_plan_validates_sd15_shapes(dry_run):
     st.pl.run(stream=0)
     assert 400 < st.n_ops <= 500             # round 2: 643 (LayerNorm / GroupNorm launches folded into the row GEMMs, q | k | V^T fused)
     kinds = unet.plan_summary()["kinds"]
-    # (round 6: the GroupNorms in front of the 20 cconv resnet convs -- levels 1 and 2 -- run inside those launches)
-    assert _lib.OP_LAYERNORM not in kinds and kinds[_lib.OP_GN_APPLY] == 22 * 2 + 1 - 20     # resnet norms + conv_norm_out only
+    assert _lib.OP_LAYERNORM not in kinds and kinds[_lib.OP_GN_APPLY] == 22 * 2 + 1      # resnet norms + conv_norm_out only
     assert abs(unet.weight_bytes() / 1e9 - 2.6) < 0.2
 
 
