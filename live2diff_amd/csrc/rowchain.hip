@@ -481,7 +481,7 @@ __global__ __launch_bounds__(C) void rowchain_head_kernel(RowHeadArgs a) {
 }
 
 template <int C, int NBP, bool TRL>
-static void launch_rh(const RowHeadArgs &a, hipStream_t s) {
+static int launch_rh(const RowHeadArgs &a, hipStream_t s) {
     constexpr size_t STG = (size_t)(C * (RC_BM + 8) > RC_BM * C ? C * (RC_BM + 8) : RC_BM * C);
     constexpr size_t LDS = (size_t)(2 * RC_BM * C + 2 * STG) * 2 + (size_t)(C + NBP * C + 2 * C + 64) * 4;
     static_assert(LDS <= 163840, "tiles do not fit the CU's LDS");
@@ -489,9 +489,13 @@ static void launch_rh(const RowHeadArgs &a, hipStream_t s) {
     bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (LDS > 65536 && !attr_done) {
         if (hipFuncSetAttribute((const void *)rowchain_head_kernel<C, NBP, TRL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
-        else (void)hipGetLastError();
+        else {
+            l2d_set_error("rowchain head: the device refused %zu bytes of dynamic LDS (hipFuncSetAttribute: %s)", LDS, hipGetErrorString(hipGetLastError()));
+            return L2D_ELAUNCH;                           // (nothing was launched)
+        }
     }
     hipLaunchKernelGGL((rowchain_head_kernel<C, NBP, TRL>), dim3(a.M / RC_BM), dim3(C), LDS, s, a);
+    return L2D_OK;
 }
 
 static int l2d_launch_rowchain_head(const l2d_op *op, hipStream_t s) {
@@ -518,10 +522,22 @@ static int l2d_launch_rowchain_head(const l2d_op *op, hipStream_t s) {
                       C, nbp, trl, a.ldx, a.ldh, a.ldo, a.T, a.G);
         return L2D_EINVAL;
     }
+    // (round-5 advisor finding) blocks read x / resA up front while other blocks already write hout / out / outT: an in-place call
+    // through the C ABI would corrupt rows silently; element offsets are formed in 64 bits but bounded like the tail's
+    {
+        const long long maxld = a.ldx > a.ldh ? a.ldx : a.ldh;
+        const void *ins[2] = {a.x, a.resA}, *outs[3] = {a.hout, a.out, a.outT};
+        bool alias = false;
+        for (const void *i_ : ins)
+            for (const void *o_ : outs) alias |= (i_ && o_ && i_ == o_);
+        if (alias || (long long)a.M * maxld >= (1ll << 40) || (long long)a.M * (a.ldo > 0 ? a.ldo : 1) >= (1ll << 40)) {
+            l2d_set_error("rowchain head(tag %d): outputs must not alias x / resA, M * ld must stay below 2^40 (M=%d)", op->tag, a.M);
+            return L2D_EINVAL;
+        }
+    }
     L2D_DRY_RETURN();
-    if (nbp == 1) launch_rh<320, 1, false>(a, s);
-    else if (trl) launch_rh<320, 3, true>(a, s);
-    else launch_rh<320, 3, false>(a, s);
+    const int rc = nbp == 1 ? launch_rh<320, 1, false>(a, s) : (trl ? launch_rh<320, 3, true>(a, s) : launch_rh<320, 3, false>(a, s));
+    if (rc != L2D_OK) return rc;
     return l2d_check_launch("rowchain head", op->tag);
 }
 

@@ -116,10 +116,15 @@ def replicate_tensors(tensors: Optional[Dict[str, torch.Tensor]], device, src: i
     size = lambda shp, dt: (_numel(shp) * esize[dt] + 15) // 16 * 16          # bytes of a tensor's slot in a bucket (16-byte aligned)
     out: Dict[str, torch.Tensor] = {}
     checksum = torch.zeros(1, dtype=torch.float64, device=device)
+    # (zero-byte tensors never enter a bucket: they are emitted directly; a bucket is never empty)
+    for k, shp, dt in items:
+        if _numel(shp) == 0:
+            out[k] = torch.empty(shp, dtype=getattr(torch, dt), device=device)
+    items = [it for it in items if _numel(it[1]) > 0]
     i = 0
     while i < len(items):
         j, n = i, 0
-        while j < len(items) and (n == 0 or n + size(items[j][1], items[j][2]) <= bucket_bytes):
+        while j < len(items) and (j == i or n + size(items[j][1], items[j][2]) <= bucket_bytes):
             n += size(items[j][1], items[j][2])
             j += 1
         shard = ((n + world - 1) // world + 15) // 16 * 16
@@ -128,8 +133,8 @@ def replicate_tensors(tensors: Optional[Dict[str, torch.Tensor]], device, src: i
             flat.zero_()
             off = 0
             for k, shp, dt in items[i:j]:
-                t = tensors[k].to(device).contiguous().reshape(-1).view(torch.uint8)
-                flat[off:off + t.numel()].copy_(t)
+                nb = _numel(shp) * esize[dt]               # straight into the flat view: no intermediate device copy beside the bucket
+                flat[off:off + nb].view(getattr(torch, dt)).view(shp).copy_(tensors[k])
                 off += size(shp, dt)
         mine = torch.empty(shard, dtype=torch.uint8, device=device)
         dist.scatter(mine, scatter_list=(list(flat.view(world, shard).unbind(0)) if rank == src else None), src=src)

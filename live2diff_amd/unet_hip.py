@@ -247,8 +247,10 @@ class HipStreamingUNet:
             if rg:
                 W[name + ".rw1"], W[name + ".rb1"] = ops.pack_rowgemm(g(pw), g(pb), g(norm + ".weight"), g(norm + ".bias"), geglu=True)
                 if chain_on and sd[pw][0].numel() == ops.ROWCHAIN_C:
-                    # the token-resident block tail (rowchain.hip) streams FF2 in the row GEMM's fragment order too (K = 4 C)
-                    W[name + ".net.2.rw"], W[name + ".net.2.rb"] = ops.pack_rowgemm(g(name + ".net.2.weight"), g(name + ".net.2.bias"))
+                    # the token-resident block tail (rowchain.hip) streams FF2 in the row GEMM's fragment order too (K = 4 C).  Its own
+                    # keys (".chw" / ".chb"): `linear()` picks the row GEMM for a layer by the presence of ".rw", and a plain K = 1280
+                    # Linear must stay on the implicit-GEMM kernel wherever the chain does not run (round-5 advisor finding)
+                    W[name + ".net.2.chw"], W[name + ".net.2.chb"] = ops.pack_rowgemm(g(name + ".net.2.weight"), g(name + ".net.2.bias"))
             if not rg or old:
                 W[name + ".w1"], W[name + ".b1"] = ops.pack_geglu(g(pw), g(pb))
             lin(name + ".net.2", old=old, lvl=lvl)
@@ -834,7 +836,7 @@ class HipStreamingUNet:
             """attention output projection + residual -> LayerNorm -> GEGLU -> FF2 + residual -> proj_out + block residual as ONE
             token-resident launch (rowchain.hip) where the level's M / 32 blocks fill the chip (C = 320); None = not here."""
             T, C = ao.H * ao.W, ao.C
-            keys = (to_out + ".rw", to_out + ".rb", ff + ".rw1", ff + ".rb1", ff + ".net.2.rw", ff + ".net.2.rb", proj_out + ".rw", proj_out + ".rb")
+            keys = (to_out + ".rw", to_out + ".rb", ff + ".rw1", ff + ".rb1", ff + ".net.2.chw", ff + ".net.2.chb", proj_out + ".rw", proj_out + ".rb")
             if not (st.rg and ops.rowchain_ok(B * T, C, T) and all(k in W for k in keys)):
                 return None
             out = new_act(C, ao.H, ao.W)

@@ -328,6 +328,24 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
     assert _lib.OP_LAYERNORM not in tot
 
 
+def test_plain_k1280_linear_stays_on_igemm_where_the_chain_does_not_run(dry_run):
+    """Round-5 advisor finding: the block chain's FF2 packing must not move the plain K = 4 C Linear to the row GEMM at a C = 320 level
+    whose M / 32 blocks do not fill the chip (48 x 48 latent, N = 2: M = 4608 < 6144) -- the measured rule keeps it on igemm."""
+    from live2diff_amd import _lib
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import unet_param_spec
+    cfg = sd15_config()
+    sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    unet = HipStreamingUNet(sd, cfg, 48, 48, 2, device="cpu")
+    del sd
+    st = unet._plan("stream", unet.prepare_cache(2))
+    ops_ = [st.pl[j] for j in range(len(st.pl))]
+    assert not any(o.kind == _lib.OP_ROWCHAIN and o.i[6] == 0 for o in ops_)                   # no chain tail at this size
+    assert not any(o.kind == _lib.OP_ROWGEMM and o.i[1] == 1280 and o.i[7] == 0 and o.i[0] == 4608 for o in ops_)
+    assert sum(1 for o in ops_ if o.kind == _lib.OP_IGEMM and o.i[0] == 1 and o.i[13] == 4608 and o.i[1] == 1280 and o.i[14] == 320) == 10
+
+
 def test_pipeline_mirror_keeps_the_reference_api_surface():
     """names the Python counterpart of `StreamAnimateDiffusionDepth` must preserve (reference
     pipeline_stream_animation_depth.py:24-666), checked on a CPU instance driven by a stand-in UNet callable -- the
