@@ -274,3 +274,59 @@ def test_skinny_linear_rows_share_one_instruction_sequence(kernels):
     assert sorted(seen) == list(range(1, 9)), seen
     for mm, (ndot, other) in seen.items():
         assert ndot == 4 * mm and not other, (mm, ndot, other)
+
+
+def test_cconv_chunk_loop_is_counted_not_drained(kernels):
+    """cconv.hip streams its weights through a register ring with PLAIN loads and relies on the compiler's waitcnt insertion to count
+    them across the rolled chunk loop (`s_waitcnt vmcnt(16..18)`: the ring stays in flight).  Two things broke that during bring-up and
+    are pinned here on the shipped ISA: (a) with the LDS-DMA builtin anywhere in the kernel the loop head waited vmcnt(0) -- the DMA is
+    inline asm now and must stay invisible to the compiler; (b) control flow inside the loop body spilled the ring.  For every cconv
+    kernel: the hot loop (the basic block run with >= 72 MFMAs and a backward branch) holds no `vmcnt(0)`, at least one counted vmcnt
+    wait per k step pair, exactly the expected MFMAs / fragment reads / weight loads, and the kernel uses no scratch."""
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    n_checked = 0
+    for co in kernels["__code_objects__"]:
+        dis = subprocess.run([objdump, "-d", co], check=True, capture_output=True, text=True).stdout
+        if "cconv_kernel" not in dis:
+            continue
+        for fn in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+            head = fn.split("\n", 1)[0]
+            if "cconv_kernel" not in head:
+                continue
+            ins, addr = [], []
+            for line in fn.split("\n")[1:]:
+                m = re.match(r"\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+                if m:
+                    ins.append(m.group(1))
+                    addr.append(int(m.group(2), 16))
+            # backward branches delimit loops: take the one whose body holds the most MFMAs
+            best = None
+            for i, t in enumerate(ins):
+                m = re.match(r"s_cbranch_\w+ (\d+)", t)
+                if not m:
+                    continue
+                off = int(m.group(1))
+                if off < 32768:
+                    continue                                    # forward branch
+                tgt = addr[i] + 4 + 4 * (off - 65536)
+                if tgt in addr:
+                    j = addr.index(tgt)
+                    body = ins[j:i + 1]
+                    inner = [re.match(r"s_cbranch_\w+ (\d+)", b) for b in body[:-1]]
+                    if any(m_ and int(m_.group(1)) >= 32768 for m_ in inner):
+                        continue                                # not an innermost loop
+                    nm = sum("v_mfma_f32_32x32x16_f16" in b for b in body)
+                    if best is None or nm > best[0]:
+                        best = (nm, body)
+            assert best is not None and best[0] == 144, (head, None if best is None else best[0])      # one chunk (KG = 2) or two (KG = 4)
+            body = best[1]
+            waits = [b for b in body if b.startswith("s_waitcnt") and "vmcnt" in b]
+            assert waits and not any(re.search(r"vmcnt\(0\)", w) for w in waits), (head, waits[:4])
+            assert all(int(re.search(r"vmcnt\((\d+)\)", w).group(1)) >= 14 for w in waits), (head, waits[:6])
+            assert sum(b.startswith("ds_read_b128") for b in body) == 72 and sum(b.startswith("global_load_dwordx4") for b in body) == 36, head
+            assert not any("scratch_" in b for b in ins) and not any("global_load_lds" in b and "ASM" in b for b in body), head
+            n_checked += 1
+    assert n_checked >= 6, n_checked
+    for n, k in kernels.items():
+        if "cconv_kernel" in n:
+            assert k["vgpr_count"] <= 256 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)

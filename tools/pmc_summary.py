@@ -1,12 +1,16 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 `--pmc` passes (rocpd SQLite databases) per kernel family.
 
-  python tools/pmc_summary.py <out.txt> <db> [<db> ...] [--traffic profiles/traffic.json]
+  python tools/pmc_summary.py <out.txt> <db> [<db> ...] [--traffic profiles/traffic.json] [--mfma profiles/mfma.json]
 
 Prints, per kernel name, the average of every collected counter per dispatch.  With --traffic, HBM bytes per
 launch are derived from FETCH_SIZE / WRITE_SIZE (kB) exactly as MI355X_MICROARCH.md section HBM prescribes for
 gfx950: FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x -> read bytes = 2 * FETCH_SIZE * 1024;
 WRITE_SIZE is used as reported (uncalibrated); the two counters come from separate passes.
+With --mfma, matrix-pipe utilisation per kernel family and per kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs; = 32 x the number
+of 32x32x16 MFMAs, 16 x the number of 16x16x32 ones) / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs) -- rocprofv3's own MfmaUtil expression
+(reduce(SQ_VALU_MFMA_BUSY_CYCLES, sum) / (reduce(GRBM_GUI_ACTIVE, max) * SIMD_NUM)); the database holds GRBM_GUI_ACTIVE summed over
+the 8 XCDs, so the per-XCD value is the sum / 8.  Separate passes, one counter each.
 """
 import collections
 import json
@@ -34,7 +38,11 @@ def family(name):
 
 def main():
     args = sys.argv[1:]
-    traffic_path = None
+    traffic_path = mfma_path = None
+    if "--mfma" in args:
+        i = args.index("--mfma")
+        mfma_path = args[i + 1]
+        del args[i:i + 2]
     if "--traffic" in args:
         i = args.index("--traffic")
         traffic_path = args[i + 1]
@@ -75,7 +83,22 @@ def main():
                          "note": "FETCH_SIZE*1024*2 (gfx950 16B/lane correction) + WRITE_SIZE*1024; separate --pmc passes"}
         with open(traffic_path, "w") as f:
             json.dump(tr, f, indent=1, sort_keys=True)
-    print("wrote", out_path, traffic_path or "")
+    if mfma_path:
+        def util(ctr):
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in ctr or "GRBM_GUI_ACTIVE" not in ctr:
+                return None
+            busy = sum(ctr["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(ctr["SQ_VALU_MFMA_BUSY_CYCLES"])
+            gui = sum(ctr["GRBM_GUI_ACTIVE"]) / len(ctr["GRBM_GUI_ACTIVE"]) / 8.0
+            return {"mfma_busy_cycles_per_launch": round(busy), "gui_active_cycles_per_launch": round(gui), "mfma_util": round(busy / (gui * 1024.0), 4),
+                    "launches_sampled": len(ctr["SQ_VALU_MFMA_BUSY_CYCLES"])}
+        mj = {"families": {k: u for k, u in ((k, util(c)) for k, c in fam.items()) if u},
+              "kernels": {k: u for k, u in ((k, util(c)) for k, c in per_kernel.items()) if u and u["mfma_busy_cycles_per_launch"] > 0},
+              "note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (GRBM_GUI_ACTIVE per XCD * 1024 SIMDs): rocprofv3's MfmaUtil "
+                      "expression; separate --pmc passes over tools/traffic_frame.py (in-frame launches, cold weights); kernels run ~1.1-1.4x "
+                      "slower under counter collection"}
+        with open(mfma_path, "w") as f:
+            json.dump(mj, f, indent=1, sort_keys=True)
+    print("wrote", out_path, traffic_path or "", mfma_path or "")
 
 
 if __name__ == "__main__":

@@ -29,3 +29,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_summary.py "$OUT/${TAG}_pmc_frame.txt" $(find /tmp/prof/FETCH_SIZE /tmp/prof/WRITE_SIZE -name "*.db") --traffic "$OUT/traffic.json"
 cat "$OUT/traffic.json" | head -40
+
+# 4. matrix-pipe utilisation (north_star: "rocprof HBM GB/s and MFMA utilisation against peak"): SQ_VALU_MFMA_BUSY_CYCLES and
+# GRBM_GUI_ACTIVE, one counter per pass, same frame replay target
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES; do
+    ( cd /tmp && FRAMES=3 timeout 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof/$c -o p -- python "$OLDPWD/tools/traffic_frame.py" \
+        > "$OLDPWD/$OUT/pmc_${c}.log" 2>&1 ) || echo "PMC pass $c failed (see $OUT/pmc_${c}.log)"
+done
+python tools/pmc_summary.py "$OUT/${TAG}_pmc_mfma.txt" $(find /tmp/prof/SQ_VALU_MFMA_BUSY_CYCLES /tmp/prof/GRBM_GUI_ACTIVE /tmp/prof/SQ_WAVE_CYCLES /tmp/prof/SQ_BUSY_CU_CYCLES -name "*.db") --mfma "$OUT/mfma.json"
+python -c "import json;d=json.load(open('$OUT/mfma.json'));print({k:v['mfma_util'] for k,v in d['families'].items()})"
