@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define L2D_ABI_VERSION 5
+#define L2D_ABI_VERSION 6
 
 enum {
     L2D_OK = 0,
@@ -193,6 +193,23 @@ enum {
  *   out = rstd (acc - mean colsum) + bias with the row statistics taken in the kernel) i21 trailing weight tiles stored transposed
  *   i22 ldt i23 non-temporal weight loads (single row tile) i30 T tokens per sample (p8)   l0 elements between samples in p8
  *   f0 eps of the LayerNorm
+ *
+ * L2D_OP_CCONV     3x3 stride-1 pad-1 convolution with the haloed activation patch resident in LDS AND the weights streamed straight into
+ *                registers (cconv.hip, round 6; reference InflatedConv3d resnet.py:57-65 as used by ResnetBlock3D :194,214 and by
+ *                Upsample3D :94-127): same result as L2D_OP_IGEMM with taps = 9, stride 1 (optionally the nearest-x2 up-sampling folded into
+ *                the gather), epi 0.  A block owns an 8 x 16 patch of OUTPUT pixels x 64 CG channels x one K slice of whole 64-channel chunks.
+ *   p0 x1 [B,Hs,Ws,C1] half   p1 x2 [B,Hs,Ws,C2] half or 0 (channel concat)   p2 w half: the weight streams of ops.pack_cconv(weight, KG)
+ *   ([Nout/64][KG][chunk][tap][u < 4/KG][half 2][64 lanes][8], k step kk = u KG + kg; + 9 k steps (18 KB) of zero padding)
+ *   p3 bias float [Nout] or 0   p4 rowbias float [*][ldrb] or 0 (row = first token of the sample / i18)   p5 residual [M][ldr] half or 0
+ *   p6 out [M][ldo] half   p7 16-byte zero page   p9 / p10, i24..i29 GroupNorm statistics of the OUTPUT as L2D_OP_IGEMM
+ *   p11 split-K counters (int32, TWO per (channel tile, patch): tickets and done; zero before and after)   p12 split-K workspace float
+ *   [tiles][S][128 * 64 CG]   (S > 1: the block with the last ticket sums the S partial tiles in the fixed order 0..S-1 with its own
+ *   registers at its own position -- bit-repeatable; it neither publishes nor re-reads its own tile)
+ *   p13 / p14 / p15, i20 = 1, i21 G, f0 eps: the conv of silu(GroupNorm(x1 | x2)) -- statistics int64 [B][G][2] as L2D_OP_GN_APPLY with
+ *   nchunk = 0, gamma / beta half [C1 + C2]; the normalisation runs in the loader waves (no GroupNorm launch, no normalised tensor)
+ *   i1 C1 i2 C2 (both % 64) i3 ldx1 i4 ldx2 i5 CinP (= C1 + C2) i6 B i7 H i8 W (OUTPUT resolution: H % 8 == 0, W % 16 == 0; the input is
+ *   [B, H >> i13, W >> i13, C]) i9 CG i10 KG ((2, 2) or (1, 4): CG KG = 4 compute waves) i11 NLD loader waves (1 | 2 | 4) i12 S K slices
+ *   (<= CinP / 64) i13 ups (0 | 1: nearest x2 of Upsample3D) i14 Nout (% 64 CG) i15 ldo i16 ldr i17 ldrb i18 rows_per_bias
  *
  * L2D_OP_ROWCHAIN  token-resident tail of a transformer block, ONE launch (rowchain.hip; reference attention.py:243-270,125-133;
  *                motion_module.py:401-435,290-297):   h2 = to_out(a) + res1;  h3 = FF2(GEGLU(LayerNorm(h2))) + h2;

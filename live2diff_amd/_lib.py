@@ -20,7 +20,7 @@ OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_LCM_STEP, OP_COPY = 10, 11, 12, 13
 OP_RING_UPDATE, OP_STREAM_SHIFT, OP_RANDN = 14, 15, 16
 OP_RESIZE_BILINEAR, OP_MINMAX, OP_DEPTH_NORM_RESIZE = 17, 18, 19
 OP_STEM7X7, OP_RESAMPLE_NHWC, OP_EW, OP_ROWGEMM, OP_PCONV, OP_WSGEMM, OP_ROWCHAIN, OP_CCONV = 20, 21, 22, 23, 24, 25, 26, 27
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class L2DError(RuntimeError):

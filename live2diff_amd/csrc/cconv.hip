@@ -68,6 +68,7 @@ struct CConvArgs {
     const h16 *pgamma, *pbeta;     // [C1 + C2]
     int pro, pG;
     float peps;
+    int par_off;                   // byte offset of the epilogue parameters + flag word in LDS (launcher: behind patch buffers / tables / parked partials / staged tile)
 #ifdef L2D_PROBES
     unsigned long long *probe;     // analysis builds: 32 s_memtime stamps per block (tools/cconv_stamps.py)
 #endif
@@ -88,7 +89,7 @@ constexpr int CC_RING = 9;                          // weight ring depth in k st
 constexpr int CC_NBUF = 3;                          // patch buffers: the loaders run two chunks ahead of the compute waves
 constexpr int CC_TBL_OFF = CC_NBUF * 24576;          // byte offset of the fused-GroupNorm (scale | shift) tables: one 512-byte entry per chunk of the slice
 constexpr int CC_TBL_MAXCH = 48;                    // ... at most this many chunks per K slice when the input GroupNorm is fused
-constexpr int CC_PAR_OFF = 100 * 1024;              // byte offset of the epilogue parameters (bias | time-embedding row) + flag word in LDS
+// (the epilogue parameters -- bias | time-embedding row -- and the flag word sit behind everything else: CConvArgs::par_off)
 }  // namespace
 
 // LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear at the LDS byte address in M0) as inline asm: with the builtin in
@@ -120,7 +121,7 @@ __device__ __forceinline__ h16x8 cc_wload(const h16 *p) {
 
 // CG: 64-channel tiles per block; KG: K groups per channel tile; NLD: loader waves
 template <int CG, int KG, int NLD>
-__global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a) {
+__global__ __launch_bounds__(64 * (CG * KG + NLD), 2) void cconv_kernel(CConvArgs a) {     // (two waves per SIMD: <= 256 registers -- the four-wave forms share a CU two blocks at a time)
     constexpr int NCW = CG * KG, UPT = 4 / KG, SPC = 9 * UPT, R = CC_RING, OWN = 4 / KG, BN = 64 * CG, NTHR = 64 * NCW;
     static_assert(KG == 1 || KG == 2 || KG == 4, "K groups");
     static_assert(SPC % R == 0, "the ring position of a k step must be static");
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
             const float *rb = a.rowbias ? a.rowbias + (long long)((bb * a.H * a.W) / a.rows_per_bias) * a.ldrb : nullptr;
 #pragma unroll
             for (int j = 0; j < CG; ++j) {
-                if (a.bias) cc_dma4((unsigned long long)(a.bias + n0 + j * 64 + lane), lds0 + CC_PAR_OFF + j * 256);
-                if (rb) cc_dma4((unsigned long long)(rb + n0 + j * 64 + lane), lds0 + CC_PAR_OFF + BN * 4 + j * 256);
+                if (a.bias) cc_dma4((unsigned long long)(a.bias + n0 + j * 64 + lane), lds0 + a.par_off + j * 256);
+                if (rb) cc_dma4((unsigned long long)(rb + n0 + j * 64 + lane), lds0 + a.par_off + BN * 4 + j * 256);
             }
         }
         // The loaders run TWO chunks ahead (three patch buffers): the DMAs of chunk c + 2 are in flight while chunk c + 1 lands and chunk
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64 * (CG * KG + NLD)) void cconv_kernel(CConvArgs a
     }
 
     const int tile = tile_n * a.npat + pat;
-    float *par = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + CC_PAR_OFF);      // bias [BN] | time-embedding row [BN]
+    float *par = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + a.par_off);      // bias [BN] | time-embedding row [BN]
     unsigned int *flag = reinterpret_cast<unsigned int *>(par + 2 * BN);
     if (a.S > 1) {
         // Split-K, reduction fused, no fences (igemm.hip explains why), and the reducing block neither publishes nor re-reads its own
@@ -707,11 +708,25 @@ int l2d_launch_cconv(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     a.nwg = (int)nwg;
-    // LDS: three patch buffers, reused by the K groups' parked partials, the staged tile and the GroupNorm reduction; parameters + flag behind
-    const size_t lds = (size_t)CC_PAR_OFF + 2 * 64 * 4 * 4 + 64;
+    // LDS: three patch buffers (+ the GroupNorm tables of a fused prologue), reused by the K groups' parked partials, the staged tile and
+    // the GroupNorm reduction; parameters + flag behind the largest of them.
+    {
+        const int NCW = CG * KG, BN = 64 * CG, OWNT = 4 / KG;
+        size_t body = (size_t)CC_NBUF * 24576 + (a.pro ? (size_t)((a.nch + a.S - 1) / a.S) * 512 : 0);
+        const size_t park = KG > 1 ? (size_t)NCW * (4 - OWNT) * 2 * 4096 : 0;
+        const size_t stage = (size_t)128 * (BN + 8) * 2;
+        const size_t gnred = (size_t)(NCW * 64 * 8 + BN) * 4;
+        if (park > body) body = park;
+        if (stage > body) body = stage;
+        if (gnred > body) body = gnred;
+        a.par_off = (int)((body + 255) & ~(size_t)255);
+    }
+    const size_t lds = (size_t)a.par_off + 2 * 64 * CG * 4 + 64;
     L2D_DRY_RETURN();
 #define CC_LAUNCH(cg, kg) do { if (NLD == 1) launch_cc<cg, kg, 1>(a, lds, s); else if (NLD == 2) launch_cc<cg, kg, 2>(a, lds, s); \
                                else launch_cc<cg, kg, 4>(a, lds, s); } while (0)
+    // ((CG 1, KG 2) -- two compute waves per block, two blocks per CU -- was built and measured in round 6: 32.0 us on the level-0
+    //  conv against 27.9 for (1, 4) and 30.4 for pconv: not instantiated)
     if (CG == 2) CC_LAUNCH(2, 2);
     else CC_LAUNCH(1, 4);
 #undef CC_LAUNCH

@@ -121,9 +121,9 @@ def main():
                     continue
                 tiles = npat * Cout // (64 * cg)
                 for S in (1, 2, 3, 4, 5, 6, 8):
-                    if S > nch or (S > 1 and tiles * S > 330) or (S == 1 and tiles < 100 and nch > 4):
+                    if S > nch or (S > 1 and tiles * S > (330 if kg != 2 or cg != 1 else 520)) or (S == 1 and tiles < 100 and nch > 4):
                         continue
-                    for nld in (2, 4):
+                    for nld in ((2, 4) if (cg, kg) != (1, 2) else (1, 2)):
                         cands.append((cg, kg, nld, S))
         packed = {}
         for sched in cands:
