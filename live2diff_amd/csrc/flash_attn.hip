@@ -264,8 +264,8 @@ int l2d_launch_flash_attn(const l2d_op *op, hipStream_t s) {
         return L2D_EINVAL;
     }
     const int variant = op->i[9];   // 0 auto (LDS-DMA ring kernel when its alignment rules hold), 1 register-staged kernel,
-                                    // 2 / 3 ring kernel with 32 / 16 query rows per wave
-    if (variant < 0 || variant > 3) {
+                                    // 2 / 3 ring kernel with 32 / 16 query rows per wave, 4 ring kernel with the pipelined loop
+    if (variant < 0 || variant > 4) {
         l2d_set_error("flash_attn(tag %d): unknown variant %d", op->tag, variant);
         return L2D_EINVAL;
     }

@@ -89,7 +89,7 @@ struct FARCfg {
     static constexpr int LDS = NS * STAGE + 1024;         // + 1 KB landing zone for the dummy DMAs
 };
 
-template <int D, int QS, int NW, int NSF>
+template <int D, int QS, int NW, int NSF, int PIPE>
 __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     using Cf = FARCfg<D, NW, NSF>;
     constexpr int KK = Cf::KK, D16 = Cf::D16, DV = Cf::DV, NS = Cf::NS, LPS = Cf::LPS, VPW = Cf::VPW, NVI = Cf::NVI;
@@ -227,6 +227,234 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) { mref[qs] = 0.f; lrow[qs] = 0.f; cinit[qs] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // V^T columns in [Tk, round_up(Tk, 8)) of the last tile may hold anything (the producer pads rows to 16 bytes): P is
+    // exactly 0 there, but 0 * NaN is not.  They are cleared in LDS after the tile has landed.
+    auto scrub_last = [&]() {
+        const int first = a.Tk & 63, last = ((a.Tk + 7) & ~7) & 63;      // key columns inside the last tile
+        if ((a.Tk & 7) == 0) return;
+        h16 *vs = smem + ((nt - 1) % NS) * STAGE_H + KH;
+        for (int r = tid; r < D; r += NT) {
+            const int sw = (r >> 1) & 7;
+            for (int c = first; c < (last == 0 ? 64 : last); ++c) vs[r * 64 + ((((c >> 3) ^ sw)) << 3) + (c & 7)] = (h16)0.0f;
+        }
+        __syncthreads();
+    };
+
+    if constexpr (PIPE != 0) {
+        // ---- software-pipelined loop (round 6; variant 4).  One wave's instruction stream of the loop above is four serial
+        // segments -- K fragments + QK^T (matrix pipe only), row maxima with two cross-lane exchanges per 16-row subtile (VALU
+        // only, a dependent chain), exponentials (VALU only), PV (matrix pipe only) -- and its partner wave on the SIMD runs the
+        // same segments: stamps (profiles/r3m_flash_tile_phases.txt) show 2 344 cycles per tile against 448 of either pipe.
+        // Here every segment pairs matrix work with INDEPENDENT vector work of the neighbouring tile, in one wave:
+        //   phase A:  S(t+1) = K(t+1).Q^T  (16 MFMAs)   beside   P(t) = exp2(S(t)) -> fp16   (32 v_exp + 16 v_cvt_pk)
+        //   phase B:  O += V^T(t).P(t)     (12 MFMAs)   beside   the reference test of S(t+1)
+        // and the test no longer reduces across lanes: a row exceeds the reference by 2^8 iff SOME lane's partial maximum
+        // does, so the fast path is 16 v_max3 + one compare (no permlane, no dependent exchange); the full row maxima are
+        // taken only inside the rarely taken rescale branch.  K fragments of tile t+1 and V^T fragments of tile t are read at
+        // the top of the iteration (tile t+1 has landed one iteration early: the ring holds t, t+1 and two tiles in flight),
+        // so no LDS latency sits between a barrier and the first MFMA.  Arithmetic and its order are those of the loop
+        // above: the outputs are bit-identical to variant 2 (asserted in tests/test_gpu_kernels.py).
+        static_assert(QS == 2 && KK <= 2 && D16 <= 3 && NS == 4, "pipelined body: 32 query rows per wave, d <= 48, 4-slot ring");
+        constexpr int EPS = 4 / KK;                                       // exponentials per QK^T MFMA (32 / (8 KK))
+        constexpr int NPV = 4 * D16;                                      // PV MFMAs per tile
+        f32x4 sA[4][2], sB[4][2];
+        h16x8 kf[KK][4], vf[2][D16], pf[2][2];
+
+        auto ld_k = [&](int slot) {
+            const h16 *st = smem + slot * STAGE_H;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[kk][ks] = l2d_ld8(st + kk * 2048 + ks * 512 + koff);
+        };
+        auto ld_v = [&](int slot) {
+            const h16 *st = smem + slot * STAGE_H;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) vf[c2][ds] = l2d_ld8(st + ds * 1024 + voff[c2]);
+        };
+        auto qk_mfma = [&](f32x4 (&S)[4][2], int e) {                     // MFMA e (0 .. 8 KK - 1) of a tile's QK^T, subtile-major
+            const int qs = e / (4 * KK), kk = (e / 4) % KK, ks = e % 4;
+            S[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk][ks], qf[qs][kk], kk == 0 ? cinit[qs] : S[ks][qs], 0, 0, 0);
+        };
+        auto mask_tail = [&](f32x4 (&S)[4][2], int kt) {                  // keys beyond Tk exist in the last tile only
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((kt * 64 + (ks >> 1) * 32 + lg * 8 + (ks & 1) * 4 + r) >= a.Tk) S[ks][qs][r] = -3.0e38f;
+        };
+        auto row_max = [&](f32x4 (&S)[4][2], float (&mx)[2]) {
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float m = fmaxf(fmaxf(S[0][qs][0], S[0][qs][1]), fmaxf(S[0][qs][2], S[0][qs][3]));
+#pragma unroll
+                for (int ks = 1; ks < 4; ++ks)
+                    m = fmaxf(fmaxf(m, fmaxf(S[ks][qs][0], S[ks][qs][1])), fmaxf(S[ks][qs][2], S[ks][qs][3]));
+                mx[qs] = far_row_max(m);
+            }
+        };
+        // Raise the reference: everything still at the old one -- O, l and the not yet exponentiated scores S -- is moved to
+        // the new one exactly once (the PV MFMAs of the previous tile are program-order BEFORE this, so O is complete).
+        auto rescale = [&](f32x4 (&S)[4][2], auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            float mx[2];
+            row_max(S, mx);
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                const float delta = FIRST ? mx[qs] : fmaxf(mx[qs], 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                mref[qs] += delta;
+                lrow[qs] *= alpha;
+#pragma unroll
+                for (int ds = 0; ds < D16; ++ds) oacc[ds][qs] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) S[ks][qs] -= delta;
+                cinit[qs] = (f32x4){-mref[qs], -mref[qs], -mref[qs], -mref[qs]};
+            }
+        };
+        float psum[2] = {0.f, 0.f};
+        auto exp_slice = [&](f32x4 (&S)[4][2], int x) {                   // exponential x (0 .. 31) of a tile, subtile-major
+            const int qs = x / 16, ks = (x % 16) / 4, r = x % 4;
+            const float pv = __builtin_amdgcn_exp2f(S[ks][qs][r]);
+            if (!Cf::ONES) psum[qs] += pv;
+            pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
+        };
+        auto pv_mfma = [&](int e) {                                       // MFMA e (0 .. NPV - 1) of a tile's PV, subtile-major
+            const int qs = e / (2 * D16), c2 = (e / D16) % 2, ds = e % D16;
+            oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][ds], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+        };
+        // lane-local maximum of a tile's 32 scores: 16 three-input maxima in two chains (one per subtile), op o = 0 .. 15
+        float lm[2];
+        auto lane_max_op = [&](f32x4 (&S)[4][2], int o) {
+            const int qs = o / 8, st = o % 8;                            // step 0: values 0..2; step k: values 2k+1, 2k+2; step 7: value 15
+            auto val = [&](int i) -> float { return S[i / 4][qs][i % 4]; };
+            if (st == 0) lm[qs] = fmaxf(fmaxf(val(0), val(1)), val(2));
+            else if (st < 7) lm[qs] = fmaxf(fmaxf(lm[qs], val(2 * st + 1)), val(2 * st + 2));
+            else lm[qs] = fmaxf(lm[qs], val(15));
+        };
+
+        // The schedule is pinned: between two `sched_barrier(0)` hipcc may order instructions, across one it may not (left to
+        // itself it hoists the maxima to just behind the MFMAs that produce their operands -- a dependency stall each -- and
+        // issues the twelve PV MFMAs back to back with no vector work beside them).  One slot = one MFMA + the vector work
+        // that runs in its shadow (the matrix pipe is busy for 16 cycles per MFMA, a plain VALU issue takes 2, v_exp ~5-8).
+        //   exponentials as 16 pairs (one v_cvt_pk each): pairs 0-1 ahead of the first MFMA, over the latency of the K
+        //   fragment reads; pairs 2-13 beside QK^T MFMAs; pairs 14-15 (last of subtile 1) beside the first PV MFMAs of
+        //   subtile 0; the lane maxima of S(t+1) beside the rest of PV, well behind the QK^T MFMAs they read.
+#define FAR_SB() __builtin_amdgcn_sched_barrier(0)
+        constexpr int NQK = 8 * KK;
+        auto exp_pair = [&](f32x4 (&S)[4][2], int pr) { exp_slice(S, 2 * pr); exp_slice(S, 2 * pr + 1); };
+        auto phase_a = [&](f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2], int vslot) {
+            exp_pair(Sc, 0);
+            exp_pair(Sc, 1);
+            FAR_SB();
+            ld_v(vslot);
+            FAR_SB();
+            // pairs 2 .. 13 over the NQK slots
+#pragma unroll
+            for (int e = 0; e < NQK; ++e) {
+                qk_mfma(Sn, e);
+#pragma unroll
+                for (int pr = 2 + (e * 12) / NQK; pr < 2 + ((e + 1) * 12) / NQK; ++pr) exp_pair(Sc, pr);
+                FAR_SB();
+            }
+        };
+        auto phase_b = [&](f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2]) {
+#pragma unroll
+            for (int e = 0; e < NPV; ++e) {
+                pv_mfma(e);
+                if (e == 0) exp_pair(Sc, 14);
+                if (e == 1) exp_pair(Sc, 15);
+                if (e >= 2) {
+#pragma unroll
+                    for (int o = ((e - 2) * 16) / (NPV - 2); o < ((e - 1) * 16) / (NPV - 2); ++o) lane_max_op(Sn, o);
+                }
+                FAR_SB();
+            }
+            if (!Cf::ONES) { lrow[0] += psum[0]; lrow[1] += psum[1]; psum[0] = 0.f; psum[1] = 0.f; }
+            if (__builtin_expect(__any(fmaxf(lm[0], lm[1]) > 8.0f), 0)) {
+                asm volatile("" ::: "memory");   // volatile: the rarely needed rescale arithmetic must not be speculated into the hot path
+                rescale(Sn, F_{});
+            }
+        };
+
+        // one iteration: tile t is exponentiated and multiplied into O, tile t + 1 gets its scores
+        auto iter = [&](int t, f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2], auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;          // t + 3 < nt - 1: refill without bounds tests
+            FAR_STAMP(t, 4);
+            if (STEADY) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); // own share of tile t + 1 landed (t + 2 in flight)
+                FAR_STAMP(t, 5);
+                __builtin_amdgcn_s_barrier();                             // tile t + 1 complete; everyone is done with tile t - 1
+                FAR_STAMP(t, 6);
+                issue(F_{});                                              // tile t + 3 into the slot of tile t - 1
+            } else {
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 == nt - 1) scrub_last();
+                if (t + 3 < nt - 1) issue(F_{});
+                else if (t + 3 == nt - 1) issue(T_{});
+            }
+            FAR_STAMP(t, 0);
+            ld_k((t + 1) & 3);
+            FAR_SB();
+            phase_a(Sc, Sn, t & 3);
+            FAR_STAMP(t, 1);
+            if (!STEADY && t + 1 == nt - 1 && nt * 64 > a.Tk) mask_tail(Sn, t + 1);
+            phase_b(Sc, Sn);
+            FAR_STAMP(t, 3);
+        };
+        auto tail = [&](f32x4 (&Sc)[4][2]) {                              // last tile: exponentials and PV only
+            ld_v((nt - 1) & 3);
+#pragma unroll
+            for (int x = 0; x < 32; ++x) exp_slice(Sc, x);
+#pragma unroll
+            for (int e = 0; e < NPV; ++e) pv_mfma(e);
+            if (!Cf::ONES) { lrow[0] += psum[0]; lrow[1] += psum[1]; }
+        };
+
+        __syncthreads();                                                  // static LDS content in place before any DMA lands
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nt) {
+                if (s == nt - 1) issue(T_{});
+                else issue(F_{});
+            }
+        if (nt >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (nt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nt == 1) scrub_last();
+        ld_k(0);
+#pragma unroll
+        for (int e = 0; e < 8 * KK; ++e) qk_mfma(sA, e);
+        if (nt == 1 && 64 > a.Tk) mask_tail(sA, 0);
+        rescale(sA, T_{});                                                // tile 0 fixes the reference
+
+        int t = 0;
+        for (; t + 6 <= nt - 1; t += 2) {                                 // t + 1 <= nt - 5: both refills are plain
+            iter(t, sA, sB, T_{});
+            iter(t + 1, sB, sA, T_{});
+        }
+        for (; t + 2 <= nt - 1; t += 2) {
+            iter(t, sA, sB, F_{});
+            iter(t + 1, sB, sA, F_{});
+        }
+        if (t == nt - 2) {
+            iter(t, sA, sB, F_{});
+            tail(sB);
+        } else {
+            tail(sA);
+        }
+    } else {
     int cp_slot = 0;
     // FIRST: tile 0 fixes the reference (no previous one); LAST: the only tile that can hold keys >= Tk.  Both are
     // compile-time so the steady-state body carries neither the masking selects nor the first-tile test.
@@ -348,21 +576,6 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         cp_slot = (cp_slot + 1 == NS) ? 0 : cp_slot + 1;
     };
 
-    // V^T columns in [Tk, round_up(Tk, 8)) of the last tile may hold anything (the producer pads rows to 16 bytes): P is
-    // exactly 0 there, but 0 * NaN is not.  They are cleared in LDS after the tile has landed.
-    auto scrub_last = [&]() {
-        const int first = a.Tk & 63, last = ((a.Tk + 7) & ~7) & 63;      // key columns inside the last tile
-        if ((a.Tk & 7) == 0) return;
-        h16 *vs = smem + ((nt - 1) % NS) * STAGE_H + KH;
-        for (int r = tid; r < D; r += NT) {
-            const int sw = (r >> 1) & 7;
-            for (int c = first; c < (last == 0 ? 64 : last); ++c) vs[r * 64 + ((((c >> 3) ^ sw)) << 3) + (c & 7)] = (h16)0.0f;
-        }
-        __syncthreads();
-    };
-
-    using T_ = std::true_type;
-    using F_ = std::false_type;
     __syncthreads();                                                      // static LDS content in place before any DMA lands
     // prologue: NS-1 tiles in flight
 #pragma unroll
@@ -412,6 +625,8 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         }
     }
 
+    }   // !PIPE
+
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         float l;
@@ -451,34 +666,38 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
 // waves per SIMD fill those slots: QS = 1 halves the registers (<= 128: four waves per SIMD), and either 8 waves share a
 // block's K / V tiles (same L2 -> LDS traffic per query as 4 x 32) or the ring is made shallow so that 4 blocks fit a CU.
 // The occupancy hint also keeps the accumulators out of the AGPR file.
-template <int D, int QS, int NW, int NSF>
+template <int D, int QS, int NW, int NSF, int PIPE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(QS == 1 && D <= 80 ? 3 : 2))) void flash_ring_kernel(FARArgs a) {
-    flash_ring_body<D, QS, NW, NSF>(a);
+    flash_ring_body<D, QS, NW, NSF, PIPE>(a);
 }
 
-template <int D, int QS, int NW, int NSF>
+template <int D, int QS, int NW, int NSF, int PIPE = 0>
 static int launch_far_q(const FARArgs &a, hipStream_t s) {
     using Cf = FARCfg<D, NW, NSF>;
     static bool attr_done_dev[L2D_MAX_DEV] = {false};
     bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (Cf::LDS > 65536 && !attr_done) {
-        if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS, NW, NSF>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
+        if (hipFuncSetAttribute((const void *)flash_ring_kernel<D, QS, NW, NSF, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) == hipSuccess)
             attr_done = true;
         else
             (void)hipGetLastError();
     }
     dim3 grid(((a.Tq + 16 * NW * QS - 1) / (16 * NW * QS)) * a.H * a.B);      // 1-D: decoded XCD-aware in the kernel
-    hipLaunchKernelGGL((flash_ring_kernel<D, QS, NW, NSF>), grid, dim3(64 * NW), Cf::LDS, s, a);
+    hipLaunchKernelGGL((flash_ring_kernel<D, QS, NW, NSF, PIPE>), grid, dim3(64 * NW), Cf::LDS, s, a);
     return L2D_OK;
 }
 
-// geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows
+// geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows; 4 = 4 waves x 32 rows, software-pipelined loop (d <= 48)
 template <int D>
 static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
     if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
         const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
         geo = (big >= 384) ? 2 : 3;
     }
+    if constexpr (D <= 48) {
+        if (geo == 4) return launch_far_q<D, 2, 4, 0, 1>(a, s);
+    }
+    if (geo == 4) geo = 2;
     if constexpr (D <= 80) {          // d = 160 with 32 query rows per wave does not fit the register file
         if (geo == 2) return launch_far_q<D, 2, 4, 0>(a, s);
     }

@@ -941,7 +941,8 @@ def layernorm(x, gamma, beta, out, *, rows, C, ldx, ldo, eps=1e-5):
 def flash_attn(q, k, vt, out, *, B, H, d, Tq, Tk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, q_off=0, k_off=0, vt_off=0,
                variant=None):
     """variant: 0 auto (LDS-DMA ring kernel), 1 register-staged kernel (round 1), 2 / 3 ring with 32 / 16 query rows per
-    wave; None = L2D_FLASH_VARIANT from the environment (A/B knob), default 0."""
+    wave, 4 ring with 32 rows per wave and the software-pipelined loop (d <= 48; other head sizes run variant 2);
+    None = L2D_FLASH_VARIANT from the environment (A/B knob), default 0."""
     op = L2dOp()
     op.kind = _lib.OP_FLASH_ATTN
     zp = zero_page(q.device)

@@ -317,12 +317,39 @@ def test_flash_attn(L, d, Tq, Tk):
     ldvt = (Tk + 7) // 8 * 8
     vt = torch.full((B, C, ldvt), float("nan"), dtype=torch.float16)     # padding columns hold garbage
     vt[:, :, :Tk] = v.transpose(1, 2)
-    for variant in (1, 2, 3):       # register-staged kernel, LDS-DMA ring kernel with 32 / 16 query rows per wave
+    outs = {}
+    for variant in (1, 2, 3, 4):    # register-staged kernel, LDS-DMA ring kernel with 32 / 16 query rows per wave, pipelined loop
         out = torch.full((B, Tq, C), float("nan"), dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=Tq, Tk=Tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
                            sq=Tq * C, sk=Tk * C, svt=C * ldvt, so=Tq * C, variant=variant))
         torch.cuda.synchronize()
         check(out, ref, what=f"flash d{d} {Tq}x{Tk} v{variant}")
+        outs[variant] = out
+    assert torch.equal(outs[4], outs[2])    # the pipelined loop reorders instructions, not arithmetic
+
+
+@pytest.mark.parametrize("d", [40, 32, 16])
+@pytest.mark.parametrize("Tk", [8, 40, 64, 77, 128, 130, 192, 200, 256, 300, 320, 384, 391, 448, 460, 512, 576, 1000])
+def test_flash_attn_pipelined_tile_counts(L, d, Tk):
+    """The pipelined loop (variant 4) has its own prologue / refill / drain structure: every key-tile count from 1 to 9 and
+    ragged last tiles (Tk % 64, Tk % 8 != 0), bit-identical to the plain ring loop (variant 2) and within tolerance of fp32."""
+    B, H, Tq = 2, 8, 200
+    C = H * d
+    q, k, v = rnd(B, Tq, C, seed=31), rnd(B, Tk, C, seed=32), rnd(B, Tk, C, seed=33)
+    qh, kh, vh = (t.float().view(B, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Tq, C)
+    ldvt = (Tk + 7) // 8 * 8
+    vt = torch.full((B, C, ldvt), float("nan"), dtype=torch.float16)
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    outs = {}
+    for variant in (2, 4):
+        out = torch.full((B, Tq, C), float("nan"), dtype=torch.float16, device=DEV)
+        L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=Tq, Tk=Tk, ldq=C, ldk=C, ldvt=ldvt, ldo=C,
+                           sq=Tq * C, sk=Tk * C, svt=C * ldvt, so=Tq * C, variant=variant))
+        torch.cuda.synchronize()
+        check(out, ref, what=f"flash pipelined d{d} Tk{Tk} v{variant}")
+        outs[variant] = out
+    assert torch.equal(outs[4], outs[2])
 
 
 def _sdpa_ref_blocks(q, k, v, H, blk=1024):
@@ -350,12 +377,15 @@ def test_flash_attn_long_sequences(L, d, T):
     q, k, v = (torch.randn(B, T, C, generator=g, device=DEV, dtype=torch.float16) for _ in range(3))
     ref = _sdpa_ref_blocks(q, k, v, H)
     vt = v.transpose(1, 2).contiguous()
-    for variant in (1, 2, 3):
+    outs = {}
+    for variant in (1, 2, 3, 4):
         out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q, k, vt, out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C, sq=T * C, sk=T * C, svt=C * T,
                            so=T * C, variant=variant))
         torch.cuda.synchronize()
         check(out, ref, what=f"flash long d{d} T{T} v{variant}")
+        outs[variant] = out
+    assert torch.equal(outs[4], outs[2])
 
 
 @pytest.mark.parametrize("d", [40, 80, 160])
@@ -376,7 +406,7 @@ def test_flash_attn_forced_rescale(L, d, scale, spike_tile):
     ref = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh
     ref = ref.transpose(1, 2).reshape(B, T, C)
     vt = v.transpose(1, 2).contiguous()
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         out = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
         L.run(L.flash_attn(q.to(DEV), k.to(DEV), vt.to(DEV), out, B=B, H=H, d=d, Tq=T, Tk=T, ldq=C, ldk=C, ldvt=T, ldo=C,
                            sq=T * C, sk=T * C, svt=C * T, so=T * C, variant=variant))
