@@ -36,6 +36,13 @@
 
 #include "common.h"
 
+// analysis builds of the pipelined loop with one component removed (tools/flash_ablate.sh; results are NOT attention):
+// -DFAR_X=mask: 1 no lane maxima / test, 2 exponentials -> multiplies, 4 no refill DMA in the steady loop, 8 no barrier there,
+// 16 no fragment reads there, 32 no PV MFMAs, 64 no QK^T MFMAs
+#ifndef FAR_X
+#define FAR_X 0
+#endif
+
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
@@ -280,7 +287,8 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         };
         auto qk_mfma = [&](f32x4 (&S)[4][2], int e) {                     // MFMA e (0 .. 8 KK - 1) of a tile's QK^T, subtile-major
             const int qs = e / (4 * KK), kk = (e / 4) % KK, ks = e % 4;
-            S[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk][ks], qf[qs][kk], kk == 0 ? cinit[qs] : S[ks][qs], 0, 0, 0);
+            if (!(FAR_X & 64)) S[ks][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kk][ks], qf[qs][kk], kk == 0 ? cinit[qs] : S[ks][qs], 0, 0, 0);
+            else S[ks][qs][0] = (float)kf[kk][ks][0] + (kk == 0 ? cinit[qs][0] : S[ks][qs][0]);
         };
         auto mask_tail = [&](f32x4 (&S)[4][2], int kt) {                  // keys beyond Tk exist in the last tile only
 #pragma unroll
@@ -323,13 +331,14 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         float psum[2] = {0.f, 0.f};
         auto exp_slice = [&](f32x4 (&S)[4][2], int x) {                   // exponential x (0 .. 31) of a tile, subtile-major
             const int qs = x / 16, ks = (x % 16) / 4, r = x % 4;
-            const float pv = __builtin_amdgcn_exp2f(S[ks][qs][r]);
+            const float pv = (FAR_X & 2) ? S[ks][qs][r] * 0.5f : __builtin_amdgcn_exp2f(S[ks][qs][r]);
             if (!Cf::ONES) psum[qs] += pv;
             pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
         };
         auto pv_mfma = [&](int e) {                                       // MFMA e (0 .. NPV - 1) of a tile's PV, subtile-major
             const int qs = e / (2 * D16), c2 = (e / D16) % 2, ds = e % D16;
-            oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][ds], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+            if (!(FAR_X & 32)) oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][ds], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
+            else oacc[ds][qs][0] += (float)pf[c2][qs][0] + (float)vf[c2][ds][0];
         };
         // lane-local maximum of a tile's 32 scores: 16 three-input maxima in two chains (one per subtile), op o = 0 .. 15
         float lm[2];
@@ -355,7 +364,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
             exp_pair(Sc, 0);
             exp_pair(Sc, 1);
             FAR_SB();
-            ld_v(vslot);
+            if (!(FAR_X & 16)) ld_v(vslot);
             FAR_SB();
             // pairs 2 .. 13 over the NQK slots
 #pragma unroll
@@ -372,14 +381,14 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 pv_mfma(e);
                 if (e == 0) exp_pair(Sc, 14);
                 if (e == 1) exp_pair(Sc, 15);
-                if (e >= 2) {
+                if (e >= 2 && !(FAR_X & 1)) {
 #pragma unroll
                     for (int o = ((e - 2) * 16) / (NPV - 2); o < ((e - 1) * 16) / (NPV - 2); ++o) lane_max_op(Sn, o);
                 }
                 FAR_SB();
             }
             if (!Cf::ONES) { lrow[0] += psum[0]; lrow[1] += psum[1]; psum[0] = 0.f; psum[1] = 0.f; }
-            if (__builtin_expect(__any(fmaxf(lm[0], lm[1]) > 8.0f), 0)) {
+            if (!(FAR_X & 1) && __builtin_expect(__any(fmaxf(lm[0], lm[1]) > 8.0f), 0)) {
                 asm volatile("" ::: "memory");   // volatile: the rarely needed rescale arithmetic must not be speculated into the hot path
                 rescale(Sn, F_{});
             }
@@ -389,12 +398,13 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         auto iter = [&](int t, f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2], auto steady_tag) {
             constexpr bool STEADY = decltype(steady_tag)::value;          // t + 3 < nt - 1: refill without bounds tests
             FAR_STAMP(t, 4);
+            FAR_STAMP(t - 1, 7);
             if (STEADY) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); // own share of tile t + 1 landed (t + 2 in flight)
                 FAR_STAMP(t, 5);
-                __builtin_amdgcn_s_barrier();                             // tile t + 1 complete; everyone is done with tile t - 1
+                if (!(FAR_X & 8)) __builtin_amdgcn_s_barrier();           // tile t + 1 complete; everyone is done with tile t - 1
                 FAR_STAMP(t, 6);
-                issue(F_{});                                              // tile t + 3 into the slot of tile t - 1
+                if (!(FAR_X & 4)) issue(F_{});                            // tile t + 3 into the slot of tile t - 1
             } else {
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -404,8 +414,9 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 else if (t + 3 == nt - 1) issue(T_{});
             }
             FAR_STAMP(t, 0);
-            ld_k((t + 1) & 3);
+            if (!(STEADY && (FAR_X & 16))) ld_k((t + 1) & 3);
             FAR_SB();
+            FAR_STAMP(t, 2);
             phase_a(Sc, Sn, t & 3);
             FAR_STAMP(t, 1);
             if (!STEADY && t + 1 == nt - 1 && nt * 64 > a.Tk) mask_tail(Sn, t + 1);
@@ -690,9 +701,9 @@ static int launch_far_q(const FARArgs &a, hipStream_t s) {
 // geometry: 0 auto; 2 = 4 waves x 32 rows; 3 = 4 waves x 16 rows; 4 = 4 waves x 32 rows, software-pipelined loop (d <= 48)
 template <int D>
 static int launch_far(const FARArgs &a, int geo, hipStream_t s) {
-    if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16
-        const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;
-        geo = (big >= 384) ? 2 : 3;
+    if (geo == 0) {   // auto: 32 query rows per wave when that still gives >= 1.5 blocks per CU, else 16; the pipelined loop
+        const long long big = (long long)((a.Tq + 127) / 128) * a.H * a.B;     // wherever it is built (d <= 48: 80 -> 72-75 us at
+        geo = (big >= 384) ? (D <= 48 ? 4 : 2) : 3;                            // T = 4096, 9.5 -> 8.5 us on the text keys)
     }
     if constexpr (D <= 48) {
         if (geo == 4) return launch_far_q<D, 2, 4, 0, 1>(a, s);
