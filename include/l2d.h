@@ -85,8 +85,9 @@ enum {
  *   i0 B i1 H i2 d i3 Tq i4 Tk i5 ldq i6 ldk i7 ldvt i8 ldo ; l0 q batch stride l1 k l2 vt l3 out
  *   p4 16-byte zero page (DMA source of keys beyond Tk; 0 selects the register-staged kernel)
  *   i9 variant: 0 auto (LDS-DMA ring kernel, flash_attn_ring.hip), 1 register-staged kernel (flash_attn.hip: the fallback for
- *   K / V^T operands that are not 16-byte aligned), 2 / 3 ring kernel with 32 / 16 query rows per wave.  V^T columns in
- *   [Tk, ldvt) may hold anything.
+ *   K / V^T operands that are not 16-byte aligned), 2 / 3 ring kernel with 32 / 16 query rows per wave, 4 ring kernel with 32
+ *   rows per wave and the software-pipelined key-tile loop (d <= 48; bit-identical to 2; what auto picks where 2 was picked
+ *   before; larger d run 2).  V^T columns in [Tk, ldvt) may hold anything.
  *
  * L2D_OP_TATTN_STREAM  fused streaming temporal attention with multi-timestep KV-cache
  *                (reference stream_motion_module.py:99-213)

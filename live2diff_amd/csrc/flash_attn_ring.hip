@@ -42,6 +42,12 @@
 #ifndef FAR_X
 #define FAR_X 0
 #endif
+// schedule choices of the pipelined loop (A/B'd with tools/flash_ablate.sh): 1 PV MFMAs alternate between the two 16-row subtiles
+// (dependent MFMAs six apart instead of three) with every exponential beside QK^T, 2 the refill DMA is issued piece by piece
+// beside the PV MFMAs instead of behind the barrier, 4 s_setprio 1 over the two MFMA phases
+#ifndef FAR_V
+#define FAR_V 0
+#endif
 
 #define L2D_GPTR(p) ((__attribute__((address_space(1))) const void *)(p))
 #define L2D_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -194,27 +200,31 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     }
 
     int is_slot = 0, is_key0 = 0;
-    auto issue = [&](auto last_tag) {                                     // LPS DMA wave-instructions, always
+    auto issue_piece = [&](int p, auto last_tag) {                        // DMA wave-instruction p (0 .. LPS - 1) of a stage
         constexpr bool LAST = decltype(last_tag)::value;                  // only the last tile can reach beyond Tk
         h16 *st = smem + is_slot * STAGE_H;
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int pc = wave + NW * i;                                 // wave-uniform piece index
+        if (p < KPW) {
+            const int i = p, pc = wave + NW * i;                          // wave-uniform piece index
             const h16 *src = (LAST && is_key0 + kkey >= a.Tk) ? a.zero : kptr[i];
             h16 *dst = pc < NKI ? st + (pc >> 2) * 2048 + (pc & 3) * 512 : dummy;
             __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
             kptr[i] += kadv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VPW; ++i) {
-            const int j = wave + NW * i;                                  // wave-uniform
+        } else {
+            const int i = p - KPW, j = wave + NW * i;                     // wave-uniform
             const h16 *src = (LAST && is_key0 + vkey[i] >= a.Tk) ? a.zero : vptr[i];
             h16 *dst = j < NVI ? st + KH + j * 512 : dummy;
             __builtin_amdgcn_global_load_lds(L2D_GPTR(src), L2D_LPTR(dst), 16, 0, 0);
             vptr[i] += vadv[i];
         }
+    };
+    auto issue_end = [&]() {
         is_slot = (is_slot + 1 == NS) ? 0 : is_slot + 1;
         is_key0 += 64;
+    };
+    auto issue = [&](auto last_tag) {                                     // LPS DMA wave-instructions, always
+#pragma unroll
+        for (int p = 0; p < LPS; ++p) issue_piece(p, last_tag);
+        issue_end();
     };
 
     // fragment read offsets (halfs, relative to the stage base); the swizzle terms are tile- and block-row-invariant
@@ -336,7 +346,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
             pf[ks >> 1][qs][(ks & 1) * 4 + r] = (h16)pv;
         };
         auto pv_mfma = [&](int e) {                                       // MFMA e (0 .. NPV - 1) of a tile's PV, subtile-major
-            const int qs = e / (2 * D16), c2 = (e / D16) % 2, ds = e % D16;
+            const int qs = (FAR_V & 1) ? (e / D16) % 2 : e / (2 * D16), c2 = (FAR_V & 1) ? e / (2 * D16) : (e / D16) % 2, ds = e % D16;
             if (!(FAR_X & 32)) oacc[ds][qs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[c2][ds], pf[c2][qs], oacc[ds][qs], 0, 0, 0);
             else oacc[ds][qs][0] += (float)pf[c2][qs][0] + (float)vf[c2][ds][0];
         };
@@ -359,6 +369,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
         //   subtile 0; the lane maxima of S(t+1) beside the rest of PV, well behind the QK^T MFMAs they read.
 #define FAR_SB() __builtin_amdgcn_sched_barrier(0)
         constexpr int NQK = 8 * KK;
+        constexpr int NPA = (FAR_V & 1) ? 14 : 12;                        // exponential pairs beside the QK^T MFMAs (after the two up front)
         auto exp_pair = [&](f32x4 (&S)[4][2], int pr) { exp_slice(S, 2 * pr); exp_slice(S, 2 * pr + 1); };
         auto phase_a = [&](f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2], int vslot) {
             exp_pair(Sc, 0);
@@ -371,22 +382,30 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
             for (int e = 0; e < NQK; ++e) {
                 qk_mfma(Sn, e);
 #pragma unroll
-                for (int pr = 2 + (e * 12) / NQK; pr < 2 + ((e + 1) * 12) / NQK; ++pr) exp_pair(Sc, pr);
+                for (int pr = 2 + (e * NPA) / NQK; pr < 2 + ((e + 1) * NPA) / NQK; ++pr) exp_pair(Sc, pr);
                 FAR_SB();
             }
         };
-        auto phase_b = [&](f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2]) {
+        auto phase_b = [&](f32x4 (&Sc)[4][2], f32x4 (&Sn)[4][2], auto dma_tag) {
+            constexpr bool DMA = decltype(dma_tag)::value;                // steady iterations with FAR_V & 2: the refill rides here
 #pragma unroll
             for (int e = 0; e < NPV; ++e) {
                 pv_mfma(e);
-                if (e == 0) exp_pair(Sc, 14);
-                if (e == 1) exp_pair(Sc, 15);
-                if (e >= 2 && !(FAR_X & 1)) {
+                if (!(FAR_V & 1) && e == 0) exp_pair(Sc, 14);
+                if (!(FAR_V & 1) && e == 1) exp_pair(Sc, 15);
+                constexpr int E0 = (FAR_V & 1) ? 0 : 2;
+                if (e >= E0 && !(FAR_X & 1)) {
 #pragma unroll
-                    for (int o = ((e - 2) * 16) / (NPV - 2); o < ((e - 1) * 16) / (NPV - 2); ++o) lane_max_op(Sn, o);
+                    for (int o = ((e - E0) * 16) / (NPV - E0); o < ((e - E0 + 1) * 16) / (NPV - E0); ++o) lane_max_op(Sn, o);
+                }
+                if (DMA) {
+#pragma unroll
+                    for (int p = 0; p < LPS; ++p)
+                        if (e == ((2 * p + 1) * NPV) / (2 * LPS)) issue_piece(p, F_{});
                 }
                 FAR_SB();
             }
+            if (DMA) issue_end();
             if (!Cf::ONES) { lrow[0] += psum[0]; lrow[1] += psum[1]; psum[0] = 0.f; psum[1] = 0.f; }
             if (!(FAR_X & 1) && __builtin_expect(__any(fmaxf(lm[0], lm[1]) > 8.0f), 0)) {
                 asm volatile("" ::: "memory");   // volatile: the rarely needed rescale arithmetic must not be speculated into the hot path
@@ -404,7 +423,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
                 FAR_STAMP(t, 5);
                 if (!(FAR_X & 8)) __builtin_amdgcn_s_barrier();           // tile t + 1 complete; everyone is done with tile t - 1
                 FAR_STAMP(t, 6);
-                if (!(FAR_X & 4)) issue(F_{});                            // tile t + 3 into the slot of tile t - 1
+                if (!(FAR_X & 4) && !(FAR_V & 2)) issue(F_{});            // tile t + 3 into the slot of tile t - 1
             } else {
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -417,10 +436,13 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
             if (!(STEADY && (FAR_X & 16))) ld_k((t + 1) & 3);
             FAR_SB();
             FAR_STAMP(t, 2);
+            if (FAR_V & 4) __builtin_amdgcn_s_setprio(1);
             phase_a(Sc, Sn, t & 3);
             FAR_STAMP(t, 1);
             if (!STEADY && t + 1 == nt - 1 && nt * 64 > a.Tk) mask_tail(Sn, t + 1);
-            phase_b(Sc, Sn);
+            if (STEADY && (FAR_V & 2) && !(FAR_X & 4)) phase_b(Sc, Sn, T_{});
+            else phase_b(Sc, Sn, F_{});
+            if (FAR_V & 4) __builtin_amdgcn_s_setprio(0);
             FAR_STAMP(t, 3);
         };
         auto tail = [&](f32x4 (&Sc)[4][2]) {                              // last tile: exponentials and PV only
