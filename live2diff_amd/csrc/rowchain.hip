@@ -10,8 +10,12 @@
 //     input, 20 KB), H (the residual stream h1 -> h2, 20 KB), G (the 4C-wide GEGLU output, 80 KB); no activation leaves the CU
 //     between the attention output and the block output;
 //   * the weights stream L2 -> VGPR in rowgemm.hip's fragment order (ops.pack_rowgemm: LayerNorm gamma / beta folded into the GEGLU
-//     projection) through a register ring of 8 k steps per 32-row tile; every wave owns 64 of the 320 output columns of a pass
-//     (2 tiles), a 4C-wide layer is 8 passes.  The whole chain is straight-line code (C is a template parameter: 280 k steps), so
+//     projection) through a register ring of 8 k steps per 32-row tile; every wave owns NT 32-column tiles of the 320 output columns
+//     of a pass, a 4C-wide layer is 8 passes.  NT = 1, TEN waves (round 6, second session): with NT = 2 the block was five waves
+//     and the SIMD that hosted two of them carried twice the MFMAs and twice the GELU / epilogue work of the others -- component
+//     ablation (tools/rowchain_time.py over tools/variant_libs.sh builds, profiles/round6_o_rowchain_ablation.txt: no weight loads
+//     at all 45.6 -> 33.6 us, GELU -> identity -5.8, deeper ring +-0) showed the launch paced by that SIMD, not by the weight
+//     ingest; ten one-tile waves sit 3 / 3 / 2 / 2 on the SIMDs: tail 45.7 -> 39.9 us, head segments 17.9 -> 16.1 us, bit-identical.  The whole chain is straight-line code (C is a template parameter: 280 k steps), so
 //     hipcc counts every fragment exactly and the NEXT pass's first ring is requested in front of the CURRENT pass's epilogue --
 //     the epilogues (bias, GELU, LDS traffic) run in the shadow of that round trip.  Biases live in LDS (staged once): a global
 //     load in an epilogue would sit behind the ring in the in-order VMEM queue and wait for all of it;
@@ -37,6 +41,22 @@ struct RowChainArgs {
     float eps;
 };
 
+#ifndef RC_RD
+#define RC_RD 8        // weight ring depth in k steps (2 KB per step and wave); A/B knob of tools/variant_libs.sh
+#endif
+// analysis builds only (tools/variant_libs.sh build rowchain RC_X "..."; results are NOT the layer chain): 1 GELU -> identity, 2 no ring
+// refills inside a k loop (the first RD steps' fragments are reused), 4 no MFMAs, 8 no activation fragment reads inside a k loop,
+// 16 no ring at all (one fragment pair loaded once per kernel)
+#ifndef RC_X
+#define RC_X 0
+#endif
+// 32-row weight tiles per wave: 2 = five waves at C = 320 (one SIMD hosts two of them), 1 = ten waves (3, 3, 2, 2 per SIMD)
+#ifndef RC_TAIL_NT
+#define RC_TAIL_NT 1
+#endif
+#ifndef RC_HEAD_NT
+#define RC_HEAD_NT 1
+#endif
 namespace {
 constexpr int RC_BM = 32;
 
@@ -65,7 +85,7 @@ __device__ __forceinline__ void rc_ring_request(h16x8 (&wr)[RD][NT], const h16 *
     for (int s = 0; s < RD; ++s) {
         asm volatile("" : "+s"(ro));
 #pragma unroll
-        for (int i = 0; i < NT; ++i) wr[s][i] = l2d_ld8(wp + (ro + (long long)i * SK * 512) + wlane);
+        for (int i = 0; i < NT; ++i) if (!(RC_X & 16)) wr[s][i] = l2d_ld8(wp + (ro + (long long)i * SK * 512) + wlane);
         ro += 512;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -84,10 +104,14 @@ __device__ __forceinline__ void rc_kloop(f32x16 (&acc)[NT], h16x8 (&wr)[RD][NT],
     xf[0] = l2d_ld8(tile + xoff[0]);
 #pragma unroll
     for (int s = 0; s < SK; ++s) {
-        if (s + 1 < SK) xf[(s + 1) & 1] = l2d_ld8(tile + ((s + 1) >> 2) * (64 * RC_BM) + xoff[(s + 1) & 3]);
+        if (s + 1 < SK && !(RC_X & 8)) xf[(s + 1) & 1] = l2d_ld8(tile + ((s + 1) >> 2) * (64 * RC_BM) + xoff[(s + 1) & 3]);
+        else if (s + 1 < SK) xf[(s + 1) & 1] = xf[s & 1];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % RD][i], xf[s & 1], acc[i], 0, 0, 0);
-        if (s + RD < SK) {
+        for (int i = 0; i < NT; ++i) {
+            if (!(RC_X & 4)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[s % RD][i], xf[s & 1], acc[i], 0, 0, 0);
+            else acc[i][s & 15] += (float)wr[s % RD][i][0] * (float)xf[s & 1][0];
+        }
+        if (s + RD < SK && !(RC_X & 18)) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) wr[s % RD][i] = l2d_ld8(wp + (wcur + (long long)i * SK * 512) + wlane);
             wcur += 512;
@@ -98,9 +122,9 @@ __device__ __forceinline__ void rc_kloop(f32x16 (&acc)[NT], h16x8 (&wr)[RD][NT],
 }
 }  // namespace
 
-template <int C>
-__global__ __launch_bounds__(C) void rowchain_tail_kernel(RowChainArgs a) {
-    constexpr int BM = RC_BM, NW = C / 64, NT = 2, SK = C / 16, H4 = 4 * C, SK2 = H4 / 16, RD = 8, NTHR = NW * 64;
+template <int C, int NT>
+__global__ __launch_bounds__(C * 2 / NT) void rowchain_tail_kernel(RowChainArgs a) {
+    constexpr int BM = RC_BM, NW = C / (32 * NT), SK = C / 16, H4 = 4 * C, SK2 = H4 / 16, RD = RC_RD, NTHR = NW * 64;
     constexpr int SLOTS = C / 8, RSTEP = NTHR / SLOTS, LPT = BM / RSTEP;        // 16-byte slots per row; rows per load pass; passes
     constexpr int NPASS = (2 * H4) / (NW * NT * 32);                            // GEGLU passes of C packed rows
     static_assert(C % 64 == 0 && NTHR % SLOTS == 0 && BM % RSTEP == 0 && (2 * H4) % (NW * NT * 32) == 0 && SK >= RD, "geometry");
@@ -121,6 +145,12 @@ __global__ __launch_bounds__(C) void rowchain_tail_kernel(RowChainArgs a) {
     // ---- the attention output a -> X, the residual stream h1 -> H: 16 bytes per lane, a row's 40 slots by 40 adjacent threads
     const int slot = tid % SLOTS, r0 = tid / SLOTS;
     h16x8 wr[RD][NT];
+    if (RC_X & 16) {
+#pragma unroll
+        for (int s = 0; s < RD; ++s)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) wr[s][i] = l2d_ld8(a.w0 + (s * NT + i) * 512 + wlane);
+    }
     {
         h16x8 va[LPT], vr[LPT];
 #pragma unroll
@@ -131,16 +161,19 @@ __global__ __launch_bounds__(C) void rowchain_tail_kernel(RowChainArgs a) {
         }
         // the biases of all four layers -> LDS (C == threads: one element of b0 / b2 / b3 and 8 of b1 per thread), requested in
         // front of the weight ring so that their LDS stores do not wait for it
-        static_assert(NTHR == C, "bias staging assumes one thread per channel");
-        const float vb0 = a.b0[tid], vb2 = a.b2[tid], vb3 = a.b3[tid];
+        static_assert(NTHR >= C, "bias staging: one thread per channel (the first C threads)");
+        const int bt = tid < C ? tid : 0;
+        const float vb0 = a.b0[bt], vb2 = a.b2[bt], vb3 = a.b3[bt];
         float vb1[2 * H4 / C];
 #pragma unroll
-        for (int k = 0; k < 2 * H4 / C; ++k) vb1[k] = a.b1[tid + C * k];
+        for (int k = 0; k < 2 * H4 / C; ++k) vb1[k] = a.b1[bt + C * k];
         __builtin_amdgcn_sched_barrier(0);
         rc_ring_request<SK, RD, NT>(wr, a.w0 + (long long)(wave * NT) * SK * 512, wlane);       // (behind the rows: rowgemm.hip)
-        bl0[tid] = vb0; bl2[tid] = vb2; bl3[tid] = vb3;
+        if (tid < C) {
+            bl0[tid] = vb0; bl2[tid] = vb2; bl3[tid] = vb3;
 #pragma unroll
-        for (int k = 0; k < 2 * H4 / C; ++k) bl1[tid + C * k] = vb1[k];
+            for (int k = 0; k < 2 * H4 / C; ++k) bl1[tid + C * k] = vb1[k];
+        }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int row = r0 + RSTEP * i;
@@ -211,7 +244,7 @@ __global__ __launch_bounds__(C) void rowchain_tail_kernel(RowChainArgs a) {
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(bp), bg = *reinterpret_cast<const f32x4 *>(bp + 8);
                 h16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (h16)((acc[i][8 * g2 + e] + bv[e]) * l2d_gelu(acc[i][8 * g2 + 4 + e] + bg[e]));
+                for (int e = 0; e < 4; ++e) o[e] = (h16)((acc[i][8 * g2 + e] + bv[e]) * ((RC_X & 1) ? acc[i][8 * g2 + 4 + e] + bg[e] : l2d_gelu(acc[i][8 * g2 + 4 + e] + bg[e])));
                 *reinterpret_cast<h16x4 *>(Gt + rc_addr((t0 + i) * 16 + 8 * g2 + 4 * lh, l32)) = o;
             }
     }
@@ -308,11 +341,11 @@ struct RowHeadArgs {
     float eps_gn, eps_ln;
 };
 
-template <int C, int NBP, bool TRL>
-__global__ __launch_bounds__(C) void rowchain_head_kernel(RowHeadArgs a) {
-    constexpr int BM = RC_BM, NW = C / 64, NT = 2, SK = C / 16, RD = 8, NTHR = NW * 64;
+template <int C, int NBP, bool TRL, int NT>
+__global__ __launch_bounds__(C * 2 / NT) void rowchain_head_kernel(RowHeadArgs a) {
+    constexpr int BM = RC_BM, NW = C / (32 * NT), SK = C / 16, RD = RC_RD, NTHR = NW * 64;
     constexpr int SLOTS = C / 8, RSTEP = NTHR / SLOTS, LPT = BM / RSTEP, NS8 = SLOTS / 8;
-    static_assert(C % 64 == 0 && NTHR % SLOTS == 0 && BM % RSTEP == 0 && NTHR == C && SK >= RD, "geometry");
+    static_assert(C % 64 == 0 && NTHR % SLOTS == 0 && BM % RSTEP == 0 && NTHR >= C && SK >= RD, "geometry");
     extern __shared__ __attribute__((aligned(16))) h16 smem[];                  // the ONLY LDS object
     h16 *X = smem, *Hh = smem + BM * C, *S0 = smem + 2 * BM * C;                // S0 | S1: staging of B's output tiles (S1: + padding for V^T)
     constexpr int STG = C * (BM + 8) > BM * C ? C * (BM + 8) : BM * C;          // halfs per staging tile (channel-major V^T rows are BM + 8 wide)
@@ -340,15 +373,18 @@ __global__ __launch_bounds__(C) void rowchain_head_kernel(RowHeadArgs a) {
             va[i] = l2d_ld8(a.x + row * a.ldx + slot * 8);
             vr[i] = resa ? l2d_ld8(a.resA + row * a.ldrA + slot * 8) : l2d_zero8();
         }
-        const float vbA = a.bA[tid];
+        const int bt = tid < C ? tid : 0;                      // (the first C threads stage the biases: one channel each)
+        const float vbA = a.bA[bt];
         float vbB[NBP];
 #pragma unroll
-        for (int k = 0; k < NBP; ++k) vbB[k] = a.bB ? a.bB[tid + C * k] : 0.f;
+        for (int k = 0; k < NBP; ++k) vbB[k] = a.bB ? a.bB[bt + C * k] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
         rc_ring_request<SK, RD, NT>(wr, a.wA + (long long)(wave * NT) * SK * 512, wlane);
-        blA[tid] = vbA;
+        if (tid < C) {
+            blA[tid] = vbA;
 #pragma unroll
-        for (int k = 0; k < NBP; ++k) blB[tid + C * k] = vbB[k];
+            for (int k = 0; k < NBP; ++k) blB[tid + C * k] = vbB[k];
+        }
         if (gnp) {
             // (rstd, -mean rstd) per channel of this block's sample, exactly as rowgemm.hip's prologue 2 (gamma / beta live in wA / bA)
             float *rstd_s = tab + 2 * C, *shf_s = rstd_s + 32;
@@ -364,9 +400,11 @@ __global__ __launch_bounds__(C) void rowchain_head_kernel(RowHeadArgs a) {
                 shf_s[tid] = -mean * rstd;
             }
             __syncthreads();
-            const int g = (int)(((float)tid + 0.5f) * ((float)a.G / (float)C));
-            tab[tid] = rstd_s[g];
-            tab[C + tid] = shf_s[g];
+            if (tid < C) {
+                const int g = (int)(((float)tid + 0.5f) * ((float)a.G / (float)C));
+                tab[tid] = rstd_s[g];
+                tab[C + tid] = shf_s[g];
+            }
             __syncthreads();
         }
 #pragma unroll
@@ -488,13 +526,13 @@ static int launch_rh(const RowHeadArgs &a, hipStream_t s) {
     static bool attr_done_dev[L2D_MAX_DEV] = {false};
     bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (LDS > 65536 && !attr_done) {
-        if (hipFuncSetAttribute((const void *)rowchain_head_kernel<C, NBP, TRL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
+        if (hipFuncSetAttribute((const void *)rowchain_head_kernel<C, NBP, TRL, RC_HEAD_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
         else {
             l2d_set_error("rowchain head: the device refused %zu bytes of dynamic LDS (hipFuncSetAttribute: %s)", LDS, hipGetErrorString(hipGetLastError()));
             return L2D_ELAUNCH;                           // (nothing was launched)
         }
     }
-    hipLaunchKernelGGL((rowchain_head_kernel<C, NBP, TRL>), dim3(a.M / RC_BM), dim3(C), LDS, s, a);
+    hipLaunchKernelGGL((rowchain_head_kernel<C, NBP, TRL, RC_HEAD_NT>), dim3(a.M / RC_BM), dim3(C * 2 / RC_HEAD_NT), LDS, s, a);
     return L2D_OK;
 }
 
@@ -548,10 +586,10 @@ static void launch_rc(const RowChainArgs &a, hipStream_t s) {
     static bool attr_done_dev[L2D_MAX_DEV] = {false};
     bool &attr_done = attr_done_dev[l2d_dev_ordinal()];
     if (LDS > 65536 && !attr_done) {
-        if (hipFuncSetAttribute((const void *)rowchain_tail_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
+        if (hipFuncSetAttribute((const void *)rowchain_tail_kernel<C, RC_TAIL_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) == hipSuccess) attr_done = true;
         else (void)hipGetLastError();
     }
-    hipLaunchKernelGGL((rowchain_tail_kernel<C>), dim3(a.M / RC_BM), dim3(C), LDS, s, a);
+    hipLaunchKernelGGL((rowchain_tail_kernel<C, RC_TAIL_NT>), dim3(a.M / RC_BM), dim3(C * 2 / RC_TAIL_NT), LDS, s, a);
 }
 
 int l2d_launch_rowchain(const l2d_op *op, hipStream_t s) {
