@@ -121,6 +121,7 @@ __device__ __forceinline__ void ws_gdrain8(h16x8 &a, h16x8 &b, h16x8 &c, h16x8 &
 
 // NT: 32-row weight tiles per consumer wave; RDS: depth of the weight register ring in stages (4 k steps each); NL: loader waves;
 // NTW: non-temporal weight loads;
+constexpr int WS_PSTR = 320;   // floats per epilogue-parameter row in LDS (bias | column sums | 4 time-embedding rows): >= the widest block (10 waves x 32 columns)
 // MAXW: launch bound in waves (sets the register budget: <= 6 waves -> 256 VGPRs, 10 -> 168)
 template <int NT, int RDS, int NL, bool NTW, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
@@ -200,14 +201,14 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                 const int cl = c < bnp ? c : bnp - 1;
                 const int cbase = c - lane;                     // wave-uniform LDS position of this instruction
                 if (a.bias) __builtin_amdgcn_global_load_lds(L2D_GPTR(a.bias + nbp + cl), L2D_LPTR(par + cbase), 4, 0, 0);
-                if (a.pro == 1) __builtin_amdgcn_global_load_lds(L2D_GPTR(a.colsum + nbp + cl), L2D_LPTR(par + 256 + cbase), 4, 0, 0);
+                if (a.pro == 1) __builtin_amdgcn_global_load_lds(L2D_GPTR(a.colsum + nbp + cl), L2D_LPTR(par + WS_PSTR + cbase), 4, 0, 0);
                 if (a.rowbias) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         int mm = m0 + 32 * mt;
                         if (mm >= a.M) mm = a.M - 1;
                         const float *rbp = a.rowbias + (long long)(mm / a.rows_per_bias) * a.ldrb;
-                        __builtin_amdgcn_global_load_lds(L2D_GPTR(rbp + nbp + cl), L2D_LPTR(par + 512 + mt * 256 + cbase), 4, 0, 0);
+                        __builtin_amdgcn_global_load_lds(L2D_GPTR(rbp + nbp + cl), L2D_LPTR(par + 2 * WS_PSTR + mt * WS_PSTR + cbase), 4, 0, 0);
                     }
                 }
             }
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                     const int ch = tp + 8 * g4 + 4 * lh;
                     f32x4 bb = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
                     if (a.bias) bb = *reinterpret_cast<const f32x4 *>(par + ch);
-                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + 256 + ch);
+                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + WS_PSTR + ch);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         float rsd = 1.f, nmr = 0.f;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                     const int ch = tp + 16 * g2 + 4 * lh;
                     const f32x4 bv = *reinterpret_cast<const f32x4 *>(par + ch), bg = *reinterpret_cast<const f32x4 *>(par + ch + 8);
                     f32x4 cv = {0.f, 0.f, 0.f, 0.f}, cg = {0.f, 0.f, 0.f, 0.f};
-                    if (a.pro == 1) { cv = *reinterpret_cast<const f32x4 *>(par + 256 + ch); cg = *reinterpret_cast<const f32x4 *>(par + 256 + ch + 8); }
+                    if (a.pro == 1) { cv = *reinterpret_cast<const f32x4 *>(par + WS_PSTR + ch); cg = *reinterpret_cast<const f32x4 *>(par + WS_PSTR + ch + 8); }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         h16x4 o;
@@ -658,11 +659,11 @@ __global__ __launch_bounds__(64 * MAXW) void wsgemm_kernel(WsArgs a) {
                     const int ch = tp + 8 * g4 + 4 * lh;
                     f32x4 bb = {0.f, 0.f, 0.f, 0.f}, cs = {0.f, 0.f, 0.f, 0.f};
                     if (a.bias) bb = *reinterpret_cast<const f32x4 *>(par + ch);
-                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + 256 + ch);
+                    if (a.pro == 1) cs = *reinterpret_cast<const f32x4 *>(par + WS_PSTR + ch);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         f32x4 b2 = bb;
-                        if (a.rowbias) b2 += *reinterpret_cast<const f32x4 *>(par + 512 + mt * 256 + ch);
+                        if (a.rowbias) b2 += *reinterpret_cast<const f32x4 *>(par + 2 * WS_PSTR + mt * WS_PSTR + ch);
                         h16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (h16)(acc[i][mt][4 * g4 + e] * rsd[mt] + nmr[mt] * cs[e] + b2[e]);
@@ -789,7 +790,7 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     // NT = 2 (two weight tiles per consumer wave: half the activation re-reads from L2) runs with a register ring of 2 stages instead
     // of 4 and at most 4 consumer waves: 234 VGPRs, no scratch (its first form, ring of 4, ran AT the 256-register limit and was
     // removed in the middle of round 4; tests/test_kernel_resources.py replays this one like the others).
-    const bool geom_ok = (NT == 1 || (NT == 2 && NW <= 4)) && NW >= 1 && NW <= 8 && (NL == 1 || NL == 2) && tiles > 0 &&
+    const bool geom_ok = (NT == 1 || (NT == 2 && NW <= 4)) && NW >= 1 && NW <= 10 && (NL == 1 || NL == 2) && tiles > 0 &&
                          (Nout % 32) == 0 && (tiles % (NW * NT)) == 0 && ntr >= 0 && ntr <= tiles && (ntr % (NW * NT)) == 0;
     const bool conv = a.taps == 9;
     if (!a.x1 || !a.w || !a.zero || a.M <= 0 || a.M >= (1 << 22) || (a.taps != 1 && a.taps != 9) || !geom_ok || a.C1 <= 0 || (a.C1 % 64) ||
@@ -839,7 +840,7 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     if (ntr > 0 && (size_t)BNp * (BM + 8) * 2 > epi) epi = (size_t)BNp * (BM + 8) * 2;
     const size_t body = ring > epi ? ring : epi;
     a.stat_off = (int)((body + 255) & ~(size_t)255);
-    const size_t lds = (size_t)a.stat_off + 2 * BM * 4 + 64 + 6 * 256 * 4;      // + bias | column sums | 4 time-embedding rows
+    const size_t lds = (size_t)a.stat_off + 2 * BM * 4 + 64 + 6 * WS_PSTR * 4;      // + bias | column sums | 4 time-embedding rows
     if (lds > 163840 || (long long)a.nm * a.ny * a.S >= (1 << 24) || (long long)a.S * (BM * BNp + 2 * BM) * 4 >= (1ll << 31)) {
         l2d_set_error("wsgemm(tag %d): tile does not fit (LDS %zu bytes, %d x %d x %d blocks)", op->tag, lds, a.nm, a.ny, a.S);
         return L2D_EINVAL;
@@ -848,6 +849,7 @@ int l2d_launch_wsgemm(const l2d_op *op, hipStream_t s) {
     const int nthr_all = 64 * (NW + NL);
     if (NT == 2) launch_ws_v<2, 2, 6>(a, NL, ntw, nthr_all, lds, s);
     else if (NW <= 4) launch_ws_v<1, 4, 6>(a, NL, ntw, nthr_all, lds, s);
-    else launch_ws_v<1, 2, 10>(a, NL, ntw, nthr_all, lds, s);
+    else if (NW <= 8) launch_ws_v<1, 2, 10>(a, NL, ntw, nthr_all, lds, s);
+    else launch_ws_v<1, 2, 12>(a, NL, ntw, nthr_all, lds, s);      // nine / ten consumer waves (3 / 3 / 2 / 2 consumers per SIMD beside two loaders)
     return l2d_check_launch("wsgemm", op->tag);
 }

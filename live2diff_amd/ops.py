@@ -482,7 +482,7 @@ def _ws_lds(NW, NT, epi, ntr, gn):
     ep = WS_BM * (BNo + 8) * 2 + ((64 * NW * 32 + BNo * 4) if gn else 0)
     if ntr:
         ep = max(ep, BNp * (WS_BM + 8) * 2)
-    return ((max(ring, ep) + 255) // 256) * 256 + 2 * WS_BM * 4 + 64 + 6 * 256 * 4
+    return ((max(ring, ep) + 255) // 256) * 256 + 2 * WS_BM * 4 + 64 + 6 * 320 * 4
 
 
 def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pro: int = 0, taps: int = 1):
@@ -499,7 +499,7 @@ def wsgemm_schedule(M: int, Ktot: int, Nout: int, ntr: int = 0, epi: int = 0, pr
     key = wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro)
     cands = []
     for nt in (1, 2):                                  # 32-row weight tiles per consumer wave (2: at most 4 consumer waves)
-        for nw in range(1, 9 if nt == 1 else 5):
+        for nw in range(1, 11 if nt == 1 else 5):
             if tiles % (nw * nt) or (ntr // 32) % (nw * nt):
                 continue
             if _ws_lds(nw, nt, epi, ntr, True) > 163840:

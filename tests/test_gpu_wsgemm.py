@@ -48,7 +48,7 @@ def _split_bufs(L, M, N, sched):
 def _geoms(tiles, ntr_tiles=0, pro=0):
     out = []
     for nt in (1, 2):
-        for nw in range(1, 9 if nt == 1 else 5):
+        for nw in range(1, 11 if nt == 1 else 5):
             if tiles % (nw * nt) == 0 and ntr_tiles % (nw * nt) == 0:
                 out.append((nw, nt))
     return out

@@ -584,7 +584,7 @@ def test_wsgemm_table_lists_are_consistent_and_gate_the_packing():
     for key, (nw, nt, nl, S) in d["shapes"].items():
         taps, M, K, N, ntr, epi, pro = (int(v) for v in key.split(","))
         tiles = N // 32
-        assert nt in (1, 2) and 1 <= nw <= (8 if nt == 1 else 4) and nl in (1, 2) and tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0, key
+        assert nt in (1, 2) and 1 <= nw <= (10 if nt == 1 else 4) and nl in (1, 2) and tiles % (nw * nt) == 0 and (ntr // 32) % (nw * nt) == 0, key
         assert 1 <= S <= max(1, K // 64) and not (ntr and S > 1), key
         assert ops.wsgemm_schedule(M, K, N, ntr, epi, pro, taps)[:4] == (nw, nt, nl, S), key
     for key in d["large"]:

@@ -83,10 +83,11 @@ def test_occupancy_budgets(kernels):
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)
     # weight-streaming GEMM: 5-6 waves per block share a CU two per SIMD (<= 256 registers), the 8-consumer form three (<= 168)
     ws = pick(r"wsgemm_kernel")
-    assert len(ws) == 12, sorted(ws)          # (NT, RDS, MAXW) = (1, 4, 6), (1, 2, 10), (2, 2, 6) x NL 1 | 2 x temporal / non-temporal loads
+    assert len(ws) == 16, sorted(ws)          # (NT, RDS, MAXW) = (1, 4, 6), (1, 2, 10), (1, 2, 12), (2, 2, 6) x NL 1 | 2 x temporal / non-temporal loads
     for n, k in ws.items():
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (n, k)
-        assert k["vgpr_count"] + k["agpr_count"] <= (168 if "Li10EEv" in n else 256), (n, k)
+        # (the 8-consumer form: 10 waves, the 10-consumer form of round 6: 12 waves -- three per SIMD either way)
+        assert k["vgpr_count"] + k["agpr_count"] <= (168 if ("Li10EEv" in n or "Li12EEv" in n) else 256), (n, k)
 
 
 def _regs(tok):
@@ -166,7 +167,7 @@ def test_wsgemm_weight_ring_registers_are_untouched_in_flight(kernels):
                     pc += 1
             assert max_depth in (8, 16), (head, max_depth)
             n_checked += 1
-    assert n_checked == 12, n_checked
+    assert n_checked == 16, n_checked
 
 
 def test_wsgemm_lds_fragment_registers_are_untouched_in_flight(kernels):
@@ -233,7 +234,7 @@ def test_wsgemm_lds_fragment_registers_are_untouched_in_flight(kernels):
                     pc += 1
             assert max_depth >= 8, (head, max_depth)
             n_checked += 1
-    assert n_checked == 12, n_checked
+    assert n_checked == 16, n_checked
 
 
 def test_no_kernel_uses_packed_fp32_math(kernels):
@@ -251,7 +252,7 @@ def test_no_kernel_uses_packed_fp32_math(kernels):
                 seen_ws += 1
             bad = sorted(set(re.findall(r"\bv_pk_\w+_f32\b", fn)))
             assert not bad, (head, bad)
-    assert seen_ws == 12, seen_ws
+    assert seen_ws == 16, seen_ws
 
 
 def test_skinny_linear_rows_share_one_instruction_sequence(kernels):
