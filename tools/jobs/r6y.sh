@@ -1,0 +1,6 @@
+# round 6, second session: evidence at the final product-code commit: the whole -m gpu suite (no -x), smoke, evidence run (bench line, kernel
+# trace, in-frame trace, HBM traffic counters, matrix-pipe counters)
+T=gpurun_out/r6y; mkdir -p $T
+timeout 1800 python -m pytest tests -m gpu -q -p no:cacheprovider > $T/pytest_gpu.log 2>&1; tail -3 $T/pytest_gpu.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $T/smoke.log 2>&1; tail -2 $T/smoke.log
+timeout 1500 bash tools/profile_round.sh round6_final2 > $T/profile_round.log 2>&1; tail -6 $T/profile_round.log
