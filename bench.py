@@ -666,6 +666,19 @@ def main():
         result["roofline"]["achieved"] = round(result["roofline"]["achieved"] * scale, 2)
         result["roofline"]["in_frame_scale"] = round(scale, 4)
         my_frac = result["roofline"]["frac"]
+        # Two families (wsgemm, igemm) have been within 1 % of each other since round 6: which one is "dominant" flips from run to run.
+        # The other one is printed beside it, priced the same way, so that the line reads the same whichever way the tie falls.
+        ranked = sorted(rows.items(), key=lambda kv_: -kv_[1]["ms"])
+        if len(ranked) > 1 and ranked[1][1]["ms"] >= 0.9 * ranked[0][1]["ms"]:
+            n2, r2 = ranked[1]
+            if n2 in MFMA_KERNELS and r2["flops"] > 0:
+                a2 = r2["flops"] / r2["launches"] / (r2["avg_us"] * 1e-6) / 1e12
+                result["roofline"]["runner_up"] = {"kernel": n2, "bound": "mfma", "ms_per_frame": round(r2["ms"], 4), "achieved": round(a2 * scale, 2),
+                                                   "unit": "TFLOP/s", "frac": round(a2 * scale / MFMA_PEAK_TFLOPS, 4)}
+            else:
+                a2 = r2["bytes"] / r2["launches"] / (r2["avg_us"] * 1e-6) / 1e9
+                result["roofline"]["runner_up"] = {"kernel": n2, "bound": "hbm", "ms_per_frame": round(r2["ms"], 4), "achieved": round(a2 * scale, 1),
+                                                   "unit": "GB/s", "frac": round(a2 * scale / HBM_PEAK_GBPS, 4)}
         # the frame's GEMM work is spread over three MFMA kernels (igemm / rowgemm / pconv) since round 3: their combined
         # rate is the figure comparable with the single igemm family of rounds 1-2
         GEMM_FAMILIES = ("igemm_kernel", "rowgemm_kernel", "pconv_kernel", "cconv_kernel", "wsgemm_kernel", "rowchain_kernel")

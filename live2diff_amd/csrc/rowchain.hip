@@ -42,7 +42,7 @@ struct RowChainArgs {
 };
 
 #ifndef RC_RD
-#define RC_RD 8        // weight ring depth in k steps (2 KB per step and wave); A/B knob of tools/variant_libs.sh
+#define RC_RD 12       // weight ring depth in k steps (1 KB per step, wave and tile); 8 / 12 / 16: the same on warm weights, 12 best on cold ones and in the frame (7.744 -> 7.710 ms, tools/jobs/r6q.sh)
 #endif
 // analysis builds only (tools/variant_libs.sh build rowchain RC_X "..."; results are NOT the layer chain): 1 GELU -> identity, 2 no ring
 // refills inside a k loop (the first RD steps' fragments are reused), 4 no MFMAs, 8 no activation fragment reads inside a k loop,
