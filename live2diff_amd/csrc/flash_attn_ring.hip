@@ -132,6 +132,20 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
     h16 *op = a.out + (long long)b * a.so + h * D;
     const int nt = (a.Tk + 63) / 64;
 
+    // ---- Q rows: requested FIRST, all of them at once and unconditionally (clamped row / column: the selects come after the data),
+    // so that their round trip runs under the LDS initialisation below.  (Until round 6 each of the QS x KK loads sat behind its own
+    // bounds branch and hipcc waited `vmcnt(0)` after every one: four serialised cold round trips in front of the first DMA --
+    // 2-4 us of a 10-13 us launch at the few-token levels and on the text keys.)
+    h16x8 qraw[QS][KK];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int qr = min(q0 + qs * 16 + li, a.Tq - 1), dc = kk * 32 + lg * 8;
+            qraw[qs][kk] = l2d_ld8(qp + (long long)qr * a.ldq + (dc < D ? dc : 0));
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- static LDS content, written once: zeros everywhere (QK^T / PV padding), ones in V^T row D of every stage
     {
         const h16x8 z = l2d_zero8();
@@ -157,7 +171,7 @@ __device__ __forceinline__ void flash_ring_body(const FARArgs &a) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const int qr = q0 + qs * 16 + li, dc = kk * 32 + lg * 8;
-                qf[qs][kk] = (qr < a.Tq && dc < D) ? l2d_ld8(qp + (long long)qr * a.ldq + dc) * sc : l2d_zero8();
+                qf[qs][kk] = (qr < a.Tq && dc < D) ? qraw[qs][kk] * sc : l2d_zero8();
             }
     }
 
