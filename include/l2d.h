@@ -187,7 +187,7 @@ enum {
  *   p11 split-K arrival counters (int32, one per (channel tile, row tile), zero before and after)   p12 split-K workspace float
  *   [tiles][S][128 * 32 NW NT + 256]   p13 colsum float [Nout]: sum_k fp16(W'[n][k]) for the LayerNorm fold (i20 = 1)
  *   i0 taps (1 | 9) i1 C1 i2 C2 (% 64) i3 ldx1 i4 ldx2 i5 CinP (= C1 + C2) i6 B i7 H i8 W (conv; W >= 8, M = B H W)
- *   i9 NW consumer waves (1..8) i10 NT weight tiles per wave (1 | 2; 2: NW <= 4) i11 NL loader waves (1 | 2) i12 S K slices
+ *   i9 NW consumer waves (1..10; 9 / 10 since round 6: 3 / 3 / 2 / 2 consumers per SIMD, one block per CU) i10 NT weight tiles per wave (1 | 2; 2: NW <= 4) i11 NL loader waves (1 | 2) i12 S K slices
  *   (fused reduction: the last arriving block sums the S slabs in order 0..S-1 -- bit-repeatable -- and runs the epilogue)
  *   i13 M i14 Nout (packed rows, % 32; (Nout / 32) % (NW NT) == 0) i15 ldo i16 ldr i17 ldrb i18 rows_per_bias (% 32)
  *   i19 epi (0 none, 1 GEGLU: Nout / 2 output columns) i20 pro (0 none, 1 LayerNorm over K folded: gamma / beta live in p2 / p3,
