@@ -8,6 +8,8 @@
 //   pass 1 (gn_stats): per-(b, pixel-chunk) partial sum / sum-of-squares for each of the G groups (fixed summation order)
 //   pass 2 (gn_apply): deterministic reduction of the partials, then y = (x-mean)*rstd*gamma+beta (-> SiLU)
 // LayerNorm replaces nn.LayerNorm (attention.py:182,199,205; motion_module.py:355,361): one wave per row.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct GNArgs {
@@ -97,21 +99,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
     const int tid = threadIdx.x;
     const int C = a.C1 + a.C2, nvc = C / 8, cpg = C / a.G;
     const int b = blockIdx.y;
-    // The first trip's operands (gamma, beta, four rows of x) do not depend on the statistics: they are requested HERE, so that
+    // The block's operands (gamma, beta, four rows of x) do not depend on the statistics: they are requested HERE, so that
     // the launch is one memory round trip deep (statistics, parameters and data in flight together) instead of three
-    // dependent ones -- these launches move 0.2-5 MB and sit on the latency floor.
+    // dependent ones -- these launches move 0.2-5 MB and sit on the latency floor.  The launcher sizes a block to exactly the
+    // four pixel-row passes requested here and gives every 2048-channel band its own blocks (blockIdx.z), so no block has a
+    // second, dependent trip (round 6: the old 16 KB blocks ran a second trip of one or two rows behind the first).
     const int t0 = blockIdx.x * pix_per_block, t1 = min(a.T, t0 + pix_per_block);
     const int cols = min(nvc, 256), PR = 256 / cols;
     const int prow = tid / cols, vcl = tid - prow * cols;
-    const bool act0 = prow < PR && vcl < nvc;
-    h16x8 gm0 = l2d_zero8(), bt0 = l2d_zero8(), v0[4];
+    const int vc = blockIdx.z * cols + vcl;
+    const bool act0 = prow < PR && vc < nvc;
+    h16x8 gm = l2d_zero8(), bt = l2d_zero8(), v0[4];
     if (act0) {
-        gm0 = l2d_ld8(a.gamma + vcl * 8);
-        bt0 = l2d_ld8(a.beta + vcl * 8);
+        gm = l2d_ld8(a.gamma + vc * 8);
+        bt = l2d_ld8(a.beta + vc * 8);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int tt = t0 + prow + u * PR;
-            v0[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vcl) : l2d_zero8();
+            v0[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
         }
     }
     if (a.nchunk == 0) {   // statistics arrive as integers in units of 2^-20 (sum) and 2^-12 (sum of squares)
@@ -147,47 +152,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
         s_rstd[tid] = rsqrtf(var + a.eps);
     }
     __syncthreads();
-    for (int cb = 0; cb < nvc; cb += cols) {
-        int vc = cb + vcl;
-        if (prow >= PR || vc >= nvc) continue;
-        float sc[8], sh[8];
-        h16x8 gm = gm0, bt = bt0;
-        if (cb) { gm = l2d_ld8(a.gamma + vc * 8); bt = l2d_ld8(a.beta + vc * 8); }
+    if (!act0) return;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int g = (vc * 8 + e) / cpg;
-            sc[e] = s_rstd[g] * (float)gm[e];
-            sh[e] = (float)bt[e] - s_mean[g] * sc[e];
-        }
-        for (int t = t0 + prow; t < t1; t += 4 * PR) {     // 4 rows per trip, loads first (see gn_stats)
-            h16x8 v[4];
-            if (cb == 0 && t == t0 + prow) {
+    for (int e = 0; e < 8; ++e) {
+        int g = (vc * 8 + e) / cpg;
+        sc[e] = s_rstd[g] * (float)gm[e];
+        sh[e] = (float)bt[e] - s_mean[g] * sc[e];
+    }
+    for (int t = t0 + prow; t < t1; t += 4 * PR) {     // 4 rows per trip, loads first (see gn_stats); one trip as launched
+        h16x8 v[4];
+        if (t == t0 + prow) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = v0[u];
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int tt = t + u * PR;
-                    v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
-                }
-            }
+            for (int u = 0; u < 4; ++u) v[u] = v0[u];
+        } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int tt = t + u * PR;
-                if (tt >= t1) break;
-                h16x8 o, rr = l2d_zero8();
-                const long long oidx = ((long long)b * a.T + tt) * C + vc * 8;
-                if (a.silu == 3) rr = l2d_ld8(a.res + oidx);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float y = (float)v[u][e] * sc[e] + sh[e];
-                    if (a.silu == 1) y = l2d_silu(y);
-                    else if (a.silu == 2) y = fmaxf(y, 0.f);
-                    else if (a.silu == 3) y = fmaxf((float)(h16)y + (float)rr[e], 0.f);   // relu(norm(x) + shortcut): ResNetV2 bottleneck
-                    o[e] = (h16)y;
-                }
-                l2d_st8(a.out + oidx, o);
+                v[u] = tt < t1 ? gn_load(a, (long long)b * a.T + tt, vc) : l2d_zero8();
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = t + u * PR;
+            if (tt >= t1) break;
+            h16x8 o, rr = l2d_zero8();
+            const long long oidx = ((long long)b * a.T + tt) * C + vc * 8;
+            if (a.silu == 3) rr = l2d_ld8(a.res + oidx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = (float)v[u][e] * sc[e] + sh[e];
+                if (a.silu == 1) y = l2d_silu(y);
+                else if (a.silu == 2) y = fmaxf(y, 0.f);
+                else if (a.silu == 3) y = fmaxf((float)(h16)y + (float)rr[e], 0.f);   // relu(norm(x) + shortcut): ResNetV2 bottleneck
+                o[e] = (h16)y;
+            }
+            l2d_st8(a.out + oidx, o);
         }
     }
 }
@@ -226,13 +226,19 @@ int l2d_launch_gn_apply(const l2d_op *op, hipStream_t s) {
     if (rc) return rc;
     L2D_DRY_RETURN();
     int C = a.C1 + a.C2;
-    // ~16 KB of activations per block (enough blocks to fill 256 CUs at the large levels), at least one pass of pixel rows
-    int ppb = (8192 + C - 1) / C;
-    int pr = 256 / ((C / 8) < 256 ? (C / 8) : 256);
+    // One trip per block: the four passes of pixel rows the kernel requests before it looks at the statistics (8-32 KB of
+    // activations per block; 340-1000 blocks at the 64 x 64 level), one grid plane per band of 2048 channels.  L2D_GN_BLOCK16K=1
+    // restores the ~16 KB blocks of rounds 3-5 (a second, dependent trip of a row or two) for A/B: profiles/round6_s_*.
+    static int old_blocks = -1;
+    if (old_blocks < 0) { const char *e = getenv("L2D_GN_BLOCK16K"); old_blocks = e ? atoi(e) : 0; }
+    int cols = (C / 8) < 256 ? (C / 8) : 256;
+    int pr = 256 / cols;
+    int ppb = old_blocks ? (8192 + C - 1) / C : 4 * pr;
     if (ppb < pr) ppb = pr;
     if (ppb > a.T) ppb = a.T;
     int nb = (a.T + ppb - 1) / ppb;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, a.B), dim3(256), 0, s, a, ppb);
+    int nz = (C / 8 + cols - 1) / cols;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nb, a.B, nz), dim3(256), 0, s, a, ppb);
     return l2d_check_launch("gn_apply", op->tag);
 }
 
