@@ -249,7 +249,7 @@ def rowchain_head(x, hout, out, *, M, C, wA, bA, wB, bB=None, passes=1, resA=Non
 
 
 ROWCHAIN_C = 320                # the width the chain kernel is instantiated for (SD-1.5 level 0)
-ROWCHAIN_MIN_BLOCKS = 192       # M / 32 blocks must fill the chip: below this the four separate launches spread better
+ROWCHAIN_MIN_BLOCKS = int(os.environ.get("L2D_ROWCHAIN_MIN_BLOCKS", "192"))       # M / 32 blocks must fill the chip: below this the four separate launches spread better
 
 
 def rowchain_ok(M: int, C: int, T: int) -> bool:
@@ -806,6 +806,38 @@ def igemm_schedule(M: int, Nout: int, Kp: int, batch: int = 1, epi: int = 0, tap
             return t, S, v
     elif key in _TUNED:
         return tuple(_TUNED[key])
+    if os.environ.get("L2D_IGEMM_HEUR", "6") == "1":
+        return _igemm_heuristic_r1(M, Nout, Kp, batch, epi)
+    return _igemm_heuristic_r6(M, Nout, Kp, batch, epi)
+
+
+def _igemm_heuristic_r6(M: int, Nout: int, Kp: int, batch: int, epi: int):
+    """Fallback schedule for shapes the tuned table does not hold (every resolution outside cfg-2), round 6: the rule that the 60
+    in-frame picks of igemm_tuned.json follow, instead of the round-1 sweep's.  What the table says: few-token launches want
+    64 x 64 tiles with K split until ~240 blocks exist (~480 for K >= 2560) but never below ~6 BK64 steps per split nor above 6
+    splits unless a split would still be longer than ~30 steps; 128 x 128 tiles + split-K only for the long 3x3 contractions
+    (K >= 8640) at >= 512 tokens; no split for GEGLU epilogues.  L2D_IGEMM_HEUR=1 restores the round-1 rule (A/B:
+    profiles/round6_u_*)."""
+    cdiv = lambda a, b: (a + b - 1) // b
+    nk64 = Kp // 64
+    t64 = cdiv(Nout, 64) * cdiv(M, 64) * batch
+    t128 = cdiv(Nout, 128) * cdiv(M, 128) * batch
+    if Nout <= 64 and M >= 16384:
+        return 2, 1, (1 if nk64 <= 18 else 2)
+    if t128 >= 384:
+        return 1, 1, (4 if t128 >= 768 else 5)
+    if epi == 1:
+        return 2, 1, 1
+    if Kp >= 8640 and M >= 512 and M * Kp >= 8_000_000:
+        return 1, max(1, min(480 // t128, nk64 // 8, 16)), 5
+    if t64 >= 256:
+        return 2, (max(1, min(nk64 // 24, 1280 // t64)) if nk64 >= 64 else 1), 1
+    target = 240 if Kp <= 1920 else 480
+    return 2, max(1, min(target // t64, max(6, cdiv(nk64, 30)), nk64 // 6, 16)), 1
+
+
+def _igemm_heuristic_r1(M: int, Nout: int, Kp: int, batch: int, epi: int):
+    """The round-1 rule (tools/igemm_sweep.py, isolated launches): kept for A/B."""
     v_small, v_big = 1, 5           # BK64 x 3 stages: in-frame best (85.3 vs 79.9 fps with x2); 128x128 BK32 x 4 for the big shapes
     cdiv = lambda a, b: (a + b - 1) // b
     nk64 = Kp // 64
