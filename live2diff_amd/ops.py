@@ -249,7 +249,10 @@ def rowchain_head(x, hout, out, *, M, C, wA, bA, wB, bB=None, passes=1, resA=Non
 
 
 ROWCHAIN_C = 320                # the width the chain kernel is instantiated for (SD-1.5 level 0)
-ROWCHAIN_MIN_BLOCKS = int(os.environ.get("L2D_ROWCHAIN_MIN_BLOCKS", "192"))       # M / 32 blocks must fill the chip: below this the four separate launches spread better
+# M / 32 blocks.  Round 5 set 192 from the BASELINE configs (256+ blocks, or cfg-1's 32); round 6 measured the gap: 144 blocks (384 x 384,
+# N = 2) 7.70 -> 7.40 ms, 154 blocks (448 x 704, N = 1) 8.34 -> 7.98 ms, 100 blocks (320 x 320, N = 2) 7.09 -> 7.00 ms with the chain
+# (profiles/round6_v_*, round6_w_*); cfg-1 (32 blocks) keeps the separate launches
+ROWCHAIN_MIN_BLOCKS = int(os.environ.get("L2D_ROWCHAIN_MIN_BLOCKS", "96"))
 
 
 def rowchain_ok(M: int, C: int, T: int) -> bool:
@@ -551,6 +554,7 @@ def _load_ws_tuned():
 # shapes -> schedule; skip = few-token shapes (M <= WS_SMALL_M) where the round-3 kernel measured faster; large = shapes with MORE
 # tokens where the weight-streaming kernel measured faster (there the round-3 kernels are the default: opt-in, not opt-out)
 _WS_TUNED, _WS_SKIP, _WS_LARGE = _load_ws_tuned()
+_WS_TUNED_M = {int(k.split(",")[1]) for k in list(_WS_TUNED) + list(_WS_SKIP)}      # token counts the tuner measured (any shape class)
 WS_SMALL_M = 1280
 
 
@@ -564,9 +568,39 @@ def wsgemm_wanted(taps: int, M: int, Ktot: int, Nout: int, ntr: int = 0, epi: in
     BASELINE configs, 2048-4608 tokens): True only where the tuner measured the weight-streaming kernel faster (`large` list) --
     an untuned resolution keeps the round-3 kernels there.  The packer follows this."""
     key = wsgemm_key(taps, M, Ktot, Nout, ntr, epi, pro)
+    # measured by the tuner?  few tokens: every candidate shape it saw is in `shapes` or `skip`; above 1280 tokens it records winners
+    # only, so there the token count stands for "this level was offered"
+    tuned = (key in _WS_TUNED or key in _WS_SKIP) if M <= WS_SMALL_M else (M in _WS_TUNED_M)
+    if not tuned and os.environ.get("L2D_WSGEMM_RULE", "1") != "0" and not os.environ.get("L2D_WSGEMM_LARGE_ALL"):
+        return _wsgemm_wanted_rule(taps, M, Ktot, Nout, ntr, epi, pro)
     if M > WS_SMALL_M and not os.environ.get("L2D_WSGEMM_LARGE_ALL"):      # (LARGE_ALL: the tuner offers every shape and measures)
         return key in _WS_LARGE
     return key not in _WS_SKIP
+
+
+def _wsgemm_wanted_rule(taps: int, M: int, Ktot: int, Nout: int, ntr: int, epi: int, pro: int) -> bool:
+    """Token counts the in-frame tuner never saw (any resolution outside the five BASELINE configs): the pattern of its picks there
+    (122 of the 150 candidate shapes of the five plans follow it; the rest are within its 3 % threshold either way).  More than 1280
+    tokens (level 1): LayerNorm + q|k|v and LayerNorm + GEGLU, the long plain contractions from 3072 tokens on, the long 3x3 convs
+    that cconv.hip does not take.  Fewer: everything at the 1280-wide levels; at 640 wide the LayerNorm + q|k|v / GEGLU layers from
+    512 tokens on and the 640 -> 1280 shortcuts; nothing at 320 wide (cfg-1: the row GEMM wins every layer of its levels 0 / 1).
+    L2D_WSGEMM_RULE=0: the pre-round-6 default (every few-token shape, nothing above 1280 tokens; profiles/round6_w_*)."""
+    K = Ktot // taps
+    if M > 4608:                # (beyond every token count the kernel was measured at; the plan's own bound is L2D_WSGEMM_MAX_M)
+        return False
+    if M > WS_SMALL_M:
+        if taps == 9:
+            return Ktot >= 5760 or M >= 3072
+        if pro == 1:
+            return K == 640 and Nout >= 1920
+        return epi == 0 and Ktot >= 960 and Nout >= 640 and M >= 3072       # (the 320-wide level was never measured on this kernel)
+    if taps == 9:
+        return True
+    if K <= 320:
+        return False
+    if K <= 640:
+        return (pro == 1 and Nout >= 1920 and M >= 512) or (pro == 0 and epi == 0 and Nout >= 2 * K)
+    return True
 
 
 def wsgemm_sizes(M: int, Nout: int, NW: int, NT: int, S: int):

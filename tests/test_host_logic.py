@@ -330,20 +330,21 @@ def test_plan_algorithmic_work_matches_survey(dry_run):
 
 def test_plain_k1280_linear_stays_on_igemm_where_the_chain_does_not_run(dry_run):
     """Round-5 advisor finding: the block chain's FF2 packing must not move the plain K = 4 C Linear to the row GEMM at a C = 320 level
-    whose M / 32 blocks do not fill the chip (48 x 48 latent, N = 2: M = 4608 < 6144) -- the measured rule keeps it on igemm."""
+    whose M / 32 blocks do not fill the chip (32 x 40 latent, N = 2: M = 2560, 80 blocks < ROWCHAIN_MIN_BLOCKS = 96; round 6 moved the
+    threshold from 192 to 96 after measuring 154, 144 and 100 blocks) -- the measured rule keeps it on igemm."""
     from live2diff_amd import _lib
     from live2diff_amd.config import sd15_config
     from live2diff_amd.unet_hip import HipStreamingUNet
     from live2diff_amd.weights import unet_param_spec
     cfg = sd15_config()
     sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
-    unet = HipStreamingUNet(sd, cfg, 48, 48, 2, device="cpu")
+    unet = HipStreamingUNet(sd, cfg, 32, 40, 2, device="cpu")
     del sd
     st = unet._plan("stream", unet.prepare_cache(2))
     ops_ = [st.pl[j] for j in range(len(st.pl))]
     assert not any(o.kind == _lib.OP_ROWCHAIN and o.i[6] == 0 for o in ops_)                   # no chain tail at this size
-    assert not any(o.kind == _lib.OP_ROWGEMM and o.i[1] == 1280 and o.i[7] == 0 and o.i[0] == 4608 for o in ops_)
-    assert sum(1 for o in ops_ if o.kind == _lib.OP_IGEMM and o.i[0] == 1 and o.i[13] == 4608 and o.i[1] == 1280 and o.i[14] == 320) == 10
+    assert not any(o.kind == _lib.OP_ROWGEMM and o.i[1] == 1280 and o.i[7] == 0 and o.i[0] == 2560 for o in ops_)
+    assert sum(1 for o in ops_ if o.kind == _lib.OP_IGEMM and o.i[0] == 1 and o.i[13] == 2560 and o.i[1] == 1280 and o.i[14] == 320) == 10
 
 
 def test_pipeline_mirror_keeps_the_reference_api_surface():
@@ -571,8 +572,9 @@ def test_wsgemm_packers_schedule_and_validation(dry_run):
 
 def test_wsgemm_table_lists_are_consistent_and_gate_the_packing():
     """wsgemm_tuned.json: `skip` (opt-out) holds few-token shapes only, `large` (opt-in, round 5) shapes above WS_SMALL_M only, every
-    schedule is one the launcher accepts for its shape; ops.wsgemm_wanted follows the lists: an UNTUNED shape is wanted below the
-    bound and not wanted above it (an unmeasured resolution keeps the round-3 kernels at its many-token levels)."""
+    schedule is one the launcher accepts for its shape; ops.wsgemm_wanted follows the lists at every token count the tuner measured; at
+    other token counts (round 6) the rule fitted to the lists decides: the 1280-wide few-token layers, LayerNorm + q|k|v / GEGLU at 640
+    wide, long plain contractions from 3072 tokens on -- and nothing at the 320-wide level or beyond 4608 tokens."""
     import json
 
     from live2diff_amd import ops
@@ -594,6 +596,9 @@ def test_wsgemm_table_lists_are_consistent_and_gate_the_packing():
     assert ops.wsgemm_wanted(1, 640, 1280, 1280)              # untuned, few tokens: the weight-streaming kernel
     assert not ops.wsgemm_wanted(1, 2304, 1280, 1280)         # untuned, many tokens: the round-3 kernels
     assert not ops.wsgemm_wanted(9, 8192, 2880, 320)          # level 0 of cfg-2: measured, lost
+    assert ops.wsgemm_wanted(1, 3200, 640, 1920, 0, 0, 1) and ops.wsgemm_wanted(1, 3200, 2560, 640)      # untuned level 1 (640 x 640 image)
+    assert not ops.wsgemm_wanted(1, 3200, 1280, 320) and not ops.wsgemm_wanted(1, 1152, 640, 640)        # 320-wide level; C -> C at 640
+    assert not ops.wsgemm_wanted(1, 2048, 2560, 640)          # a token count the tuner saw: the lists decide (igemm kept this one)
 
 
 def test_cconv_patch_image_is_bank_conflict_free():
