@@ -211,6 +211,9 @@ def test_sd15_width_other_baseline_configs(golden, sd15_weights, name, h, w, N, 
     ("cfg-5: 1024x576, N = 2, L = 40 (17.1 GB)", 72, 128, 2, 40, 8),
     ("cfg-4: 512x512, N = 4, L = 16 (6.08 GB)", 64, 64, 4, 16, 8),
     ("cfg-1: 256x256, N = 1, L = 4 sink + 8 rolling (0.29 GB)", 32, 32, 1, 12, 4),
+    # a resolution NO table holds (round 6): every schedule comes from the fallback rules (igemm refit, wsgemm_wanted rule, chain kernel at
+    # 144 blocks), levels 2 / 3 are 12 x 12 / 6 x 6 pixels (no whole 32-token tiles per sample: GroupNorm statistics kernel, separate LayerNorm)
+    ("untuned: 384x384, N = 2, L = 16 (1.71 GB)", 48, 48, 2, 16, 8),
 ])
 def test_full_size_frame_against_oracle(sd15_weights, name, h, w, N, L, S):
     """All five BASELINE configs at FULL size (SD-1.5 widths, the latent, window and cache sizes the numbers are quoted on -- and
