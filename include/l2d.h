@@ -76,6 +76,9 @@ enum {
  *   p0 x1 p1 x2|0 p2 partial[B][nchunk][G][2] float  (apply: p3 gamma half, p4 beta half, p5 out half)
  *   i0 B i1 T i2 C1 i3 C2 i4 ld1 i5 ld2 i6 G i7 nchunk i8 silu  f0 eps
  *   GN_APPLY with nchunk = 0: p6 = int64 [B][G][2] fixed-point accumulators filled by the producing igemm launches (above)
+ *   GN_APPLY with nchunk = 0 and p6 = 0 (p2 unused): the one-launch form for small tensors -- a block holds all T rows of a band of whole
+ *   groups (lcm(C / G, 8) <= 128 channels, <= 4 groups) in registers, statistics and apply in the same launch; refused (L2D_EINVAL) when
+ *   T * band / 8 exceeds 16 vectors per thread of 256
  *
  * L2D_OP_LAYERNORM  p0 x [rows][ld] p1 gamma p2 beta p3 out [rows][C] ; i0 rows i1 C i2 ldx i3 ldo; f0 eps
  *

@@ -192,6 +192,105 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a, int pix_per_blo
     }
 }
 
+// One-launch GroupNorm for SMALL tensors (round 6, third session): gn_apply with nchunk == 0 and no accumulator.  Levels whose tokens
+// per sample are no whole number of GEMM tiles (12 x 12, 6 x 6, 10 x 10 ... pixels: every resolution outside the tuned ones) cannot take
+// their statistics from the producers' epilogues and paid two launches per GroupNorm (gn_stats + gn_apply: 2 x ~4.8 us for 20-370 KB).
+// Here a block owns (sample, band of whole groups = lcm(cpg, 8) channels) over ALL T pixel rows: its T * band / 8 vectors (at most 16
+// per thread) stay in registers between the statistics and the apply pass -- one read, one launch.  Thread -> (fixed 8-channel column,
+// pixel rows prow + j * PR), so the group of each of its 8 channels is a per-thread constant; per-thread sums meet through a fixed
+// shuffle tree and four LDS slots (no float atomics: bit-repeatable).  Same statistics formula and apply arithmetic as gn_apply.
+__global__ __launch_bounds__(256) void gn_self_kernel(GNArgs a, int band) {
+    constexpr int NV = 16, NGB = 4;                 // vectors per thread, groups per band (launcher checks both bounds)
+    __shared__ float s_w[4][2 * NGB];
+    __shared__ float s_mean[NGB], s_rstd[NGB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C1 + a.C2, cpg = C / a.G;
+    const int b = blockIdx.y, nvb = band >> 3, PR = 256 / nvb, ng = band / cpg;
+    const int prow = tid / nvb, vcl = tid - prow * nvb;
+    const bool act = prow < PR;
+    const int vc = blockIdx.x * nvb + vcl;
+    int ge[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ge[e] = (vcl * 8 + e) / cpg;
+    h16x8 gm = l2d_zero8(), bt = l2d_zero8(), v[NV];
+    if (act) {
+        gm = l2d_ld8(a.gamma + vc * 8);
+        bt = l2d_ld8(a.beta + vc * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {                  // every load of the block goes out before the first sum
+        const int t = prow + j * PR;
+        v[j] = (act && t < a.T) ? gn_load(a, (long long)b * a.T + t, vc) : l2d_zero8();
+    }
+    float se[8], qe[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { se[e] = 0.f; qe[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[j][e]; se[e] += f; qe[e] = fmaf(f, f, qe[e]); }
+    float sg[NGB], qg[NGB];
+#pragma unroll
+    for (int g = 0; g < NGB; ++g) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s += ge[e] == g ? se[e] : 0.f; q += ge[e] == g ? qe[e] : 0.f; }
+        sg[g] = l2d_wave_sum(s);
+        qg[g] = l2d_wave_sum(q);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < NGB; ++g) { s_w[wave][g] = sg[g]; s_w[wave][NGB + g] = qg[g]; }
+    }
+    __syncthreads();
+    if (tid < ng) {
+        const float s = (s_w[0][tid] + s_w[1][tid]) + (s_w[2][tid] + s_w[3][tid]);
+        const float q = (s_w[0][NGB + tid] + s_w[1][NGB + tid]) + (s_w[2][NGB + tid] + s_w[3][NGB + tid]);
+        const float inv = 1.0f / ((float)a.T * (float)cpg);
+        const float mean = s * inv;
+        const float var = fmaxf(q * inv - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + a.eps);
+    }
+    __syncthreads();
+    if (!act) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = s_rstd[ge[e]] * (float)gm[e];
+        sh[e] = (float)bt[e] - s_mean[ge[e]] * sc[e];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int t = prow + j * PR;
+        if (t >= a.T) break;
+        h16x8 o, rr = l2d_zero8();
+        const long long oidx = ((long long)b * a.T + t) * C + vc * 8;
+        if (a.silu == 3) rr = l2d_ld8(a.res + oidx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[j][e] * sc[e] + sh[e];
+            if (a.silu == 1) y = l2d_silu(y);
+            else if (a.silu == 2) y = fmaxf(y, 0.f);
+            else if (a.silu == 3) y = fmaxf((float)(h16)y + (float)rr[e], 0.f);
+            o[e] = (h16)y;
+        }
+        l2d_st8(a.out + oidx, o);
+    }
+}
+
+// band (channels) of the one-launch form for this shape, or 0 when it does not fit: whole groups, a multiple of 8 channels, at most 4
+// groups and 128 channels per band, at most 16 vectors per thread
+static int gn_self_band(int T, int C, int G) {
+    if (G <= 0 || C % G) return 0;
+    const int cpg = C / G;
+    int band = cpg;
+    while (band % 8) band += cpg;                   // lcm(cpg, 8)
+    if (band > 128 || band / cpg > 4 || C % band) return 0;
+    const int pr = 256 / (band / 8);
+    return (T + pr - 1) / pr <= 16 ? band : 0;
+}
+
 static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
     a.x1 = (const h16 *)op->p[0]; a.x2 = (const h16 *)op->p[1]; a.partial = (float *)op->p[2];
     a.gamma = (const h16 *)op->p[3]; a.beta = (const h16 *)op->p[4]; a.out = (h16 *)op->p[5];
@@ -201,8 +300,15 @@ static int gn_args(const l2d_op *op, GNArgs &a, bool apply) {
     a.res = (const h16 *)op->p[7];
     int C = a.C1 + a.C2;
     if (apply && a.nchunk == 0 && a.acc) a.partial = (float *)a.acc;      // accumulator mode: no partial buffer
+    const bool self = apply && a.nchunk == 0 && !a.acc;                   // one-launch form: statistics inside the launch
+    if (self) a.partial = (float *)a.x1;                                  // (unused; passes the pointer check below)
+    if (self && !gn_self_band(a.T, C, a.G)) {
+        l2d_set_error("groupnorm(tag %d): nchunk = 0 without accumulators is the one-launch form for small tensors (whole groups in bands of "
+                      "<= 128 channels, <= 4 groups per band, T * band / 8 <= 4096 vectors); T=%d C=%d G=%d does not fit", op->tag, a.T, C, a.G);
+        return L2D_EINVAL;
+    }
     if (!a.x1 || !a.partial || a.B <= 0 || a.T <= 0 || a.G <= 0 || a.G > 32 || (C % a.G) || (a.C1 % 8) || (a.C2 % 8) ||
-        (a.C2 > 0 && !a.x2) || a.nchunk < 0 || (a.nchunk == 0 && !(apply && a.acc)) || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
+        (a.C2 > 0 && !a.x2) || a.nchunk < 0 || (a.nchunk == 0 && !apply) || a.nchunk > a.T || C / 8 > 512 || (a.ld1 % 8) || (a.C2 > 0 && (a.ld2 % 8)) ||
         (apply && (!a.gamma || !a.beta || !a.out || a.silu < 0 || a.silu > 3 || (a.silu == 3 && !a.res)))) {
         l2d_set_error("groupnorm(tag %d): invalid arguments (B=%d T=%d C1=%d C2=%d G=%d nchunk=%d)", op->tag, a.B, a.T,
                       a.C1, a.C2, a.G, a.nchunk);
@@ -226,6 +332,11 @@ int l2d_launch_gn_apply(const l2d_op *op, hipStream_t s) {
     if (rc) return rc;
     L2D_DRY_RETURN();
     int C = a.C1 + a.C2;
+    if (a.nchunk == 0 && !a.acc) {
+        const int band = gn_self_band(a.T, C, a.G);
+        hipLaunchKernelGGL(gn_self_kernel, dim3(C / band, a.B), dim3(256), 0, s, a, band);
+        return l2d_check_launch("gn_self", op->tag);
+    }
     // One trip per block: the four passes of pixel rows the kernel requests before it looks at the statistics (8-32 KB of
     // activations per block; 340-1000 blocks at the 64 x 64 level), one grid plane per band of 2048 channels.  L2D_GN_BLOCK16K=1
     // restores the ~16 KB blocks of rounds 3-5 (a second, dependent trip of a row or two) for A/B: profiles/round6_s_*.

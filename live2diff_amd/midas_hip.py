@@ -192,6 +192,9 @@ class HipMidas:
                 st.gn_layers += 1
                 add(ops.gn_apply(x, None, W[name + ".g"], W[name + ".beta"], out, eps=1e-5, silu=act, B=B, T=T, C1=C, ld1=C, G=G, nchunk=0,
                                  acc_ptr=acc_ptr, res=res))
+            elif ops.gn_self_ok(T, C, G):           # small tensor behind split-K tiles: statistics + apply in one launch (norm.hip, round 6)
+                add(ops.gn_apply(x, None, W[name + ".g"], W[name + ".beta"], out, eps=1e-5, silu=act, B=B, T=T, C1=C, ld1=C, G=G, nchunk=0,
+                                 res=res))
             else:
                 nchunk = max(1, min(64, T // 16))
                 partial = ar.alloc(B * nchunk * G * 2, torch.float32)

@@ -976,9 +976,26 @@ def gn_stats(x1, partial, *, B, T, C1, ld1, G, nchunk, x2=None, C2=0, ld2=0):
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_ADD_RELU = 0, 1, 2, 3
 
 
+def gn_self_ok(T: int, C: int, G: int) -> bool:
+    """Shapes the ONE-launch GroupNorm takes (norm.hip gn_self_kernel: gn_apply with nchunk = 0 and no accumulator): a block holds all T
+    pixel rows of a band of whole groups (lcm(cpg, 8) <= 128 channels, <= 4 groups) in registers, <= 16 vectors per thread.
+    L2D_GN_SELF=0 keeps the two-launch fallback (A/B)."""
+    if os.environ.get("L2D_GN_SELF", "1") == "0" or G <= 0 or C % G:
+        return False
+    cpg = C // G
+    band = cpg
+    while band % 8:
+        band += cpg
+    if band > 128 or band // cpg > 4 or C % band:
+        return False
+    pr = 256 // (band // 8)
+    return -(-T // pr) <= 16
+
+
 def gn_apply(x1, partial, gamma, beta, out, *, B, T, C1, ld1, G, nchunk, eps, silu, x2=None, C2=0, ld2=0, acc_ptr=None, res=None):
     """nchunk = 0 + acc_ptr: the statistics come from the fixed-point accumulators [B][G][2] int64 that the producing igemm
-    launches filled (igemm `gn_target`), `partial` is unused (None)."""
+    launches filled (igemm `gn_target`), `partial` is unused (None).  nchunk = 0 WITHOUT acc_ptr (and partial None): the one-launch
+    form for small tensors -- statistics inside the launch (gn_self_ok)."""
     op = L2dOp()
     op.kind = _lib.OP_GN_APPLY
     op.p[0], op.p[1], op.p[2] = _ptr(_h(x1)), _ptr(x2), _ptr(partial)

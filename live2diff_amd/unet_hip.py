@@ -624,6 +624,13 @@ class HipStreamingUNet:
                                  ld1=x.C, G=G, nchunk=0, x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2,
                                  acc_ptr=acc_ptr))
                 return out
+            if ops.gn_self_ok(T, x.C + C2, G):
+                # small tensor whose producers cannot deliver the statistics (tokens per sample are no whole number of their tiles: any
+                # resolution with 12 x 12, 6 x 6, 10 x 10 ... pixel levels): statistics + apply in ONE launch, the tensor read once
+                st.gn_self_launches += 1
+                add(ops.gn_apply(x.buf, None, gam, bet, out.buf, eps=eps, silu=silu, B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=0,
+                                 x2=(x2.buf if x2 is not None else None), C2=C2, ld2=C2))
+                return out
             nchunk = max(1, min(64, T // 16))
             partial = ar.alloc(B * nchunk * G * 2, torch.float32)
             kw = dict(B=B, T=T, C1=x.C, ld1=x.C, G=G, nchunk=nchunk, x2=(x2.buf if x2 is not None else None), C2=C2,
@@ -1087,7 +1094,7 @@ class HipStreamingUNet:
         cur[0] = pl
         # ---- GroupNorm statistics accumulators (one [B][G][2] int64 block per fused GroupNorm), zeroed once per frame
         st.gn_fuse = os.environ.get("L2D_GN_FUSE", "1") != "0"
-        st.gn_layers, st.gn_stats_launches = 0, 0
+        st.gn_layers, st.gn_stats_launches, st.gn_self_launches = 0, 0, 0
         st.gn_acc = torch.zeros(96, B, G, 2, dtype=torch.int64, device=dev)
         st.gn_zero = torch.zeros_like(st.gn_acc)
         zero_op = add(ops.copy(st.gn_zero, st.gn_acc, st.gn_acc.numel() * 8)) if st.gn_fuse else None
@@ -1275,4 +1282,4 @@ class HipStreamingUNet:
         kinds = {}
         for j in range(len(st.pl)):
             kinds[st.pl[j].kind] = kinds.get(st.pl[j].kind, 0) + 1
-        return dict(n_ops=len(st.pl), n_cond_ops=len(st.cond_pl), gn_fused=st.gn_layers, gn_stats_launches=st.gn_stats_launches, kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())
+        return dict(n_ops=len(st.pl), n_cond_ops=len(st.cond_pl), gn_fused=st.gn_layers, gn_stats_launches=st.gn_stats_launches, gn_self_launches=st.gn_self_launches, kinds=kinds, arena_bytes=st.arena_bytes, weight_bytes=self.weight_bytes())

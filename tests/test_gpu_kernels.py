@@ -231,6 +231,55 @@ def test_groupnorm(L, C1, C2, T, silu):
     check(out, ref, what=f"groupnorm {C1}+{C2} T{T}")
 
 
+@pytest.mark.parametrize("C1,C2,T,silu", [(1280, 0, 144, True), (1280, 1280, 36, True), (1280, 640, 144, True), (640, 0, 576, True),
+                                          (320, 0, 100, False), (640, 320, 144, True), (64, 0, 16, False), (2560, 0, 400, True)])
+def test_groupnorm_one_launch(L, C1, C2, T, silu):
+    """gn_apply with nchunk = 0 and no accumulator (norm.hip gn_self_kernel, round 6): statistics and apply in one launch for the small
+    tensors whose producers cannot deliver the statistics (pixel counts per sample that are no whole GEMM tiles: 12 x 12, 6 x 6, 10 x 10,
+    20 x 20 ...).  Group sizes 2 / 10 / 20 / 30 / 40 / 60 / 80 (bands of 1-4 whole groups, a group may straddle the two inputs of a
+    concat).  Against F.group_norm in fp32, against the two-launch path, and bit-repeatable."""
+    B, G, eps = 2, 32, 1e-5
+    C = C1 + C2
+    assert L.gn_self_ok(T, C, G)
+    x1 = rnd(B, T, C1, seed=1) + 0.5
+    x2 = rnd(B, T, C2, seed=2) * 2 if C2 else None
+    gm, bt = (1 + 0.1 * rnd(C, seed=3).float()).half(), (0.1 * rnd(C, seed=4).float()).half()
+    xc = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(xc.float().permute(0, 2, 1), G, gm.float(), bt.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    x1d, x2d, gmd, btd = x1.to(DEV), (x2.to(DEV) if C2 else None), gm.to(DEV), bt.to(DEV)
+    kw = dict(B=B, T=T, C1=C1, ld1=C1, G=G, x2=x2d, C2=C2, ld2=C2)
+    out = torch.full((B, T, C), float("nan"), dtype=torch.float16, device=DEV)
+    L.run(L.gn_apply(x1d, None, gmd, btd, out, eps=eps, silu=silu, nchunk=0, **kw))
+    torch.cuda.synchronize()
+    check(out, ref, what=f"one-launch groupnorm {C1}+{C2} T{T}")
+    out2 = torch.full((B, T, C), float("nan"), dtype=torch.float16, device=DEV)
+    L.run(L.gn_apply(x1d, None, gmd, btd, out2, eps=eps, silu=silu, nchunk=0, **kw))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    nchunk = max(1, min(64, T // 16))
+    partial = torch.empty(B * nchunk * G * 2, dtype=torch.float32, device=DEV)
+    out3 = torch.empty(B, T, C, dtype=torch.float16, device=DEV)
+    L.run(L.gn_stats(x1d, partial, nchunk=nchunk, **kw))
+    L.run(L.gn_apply(x1d, partial, gmd, btd, out3, eps=eps, silu=silu, nchunk=nchunk, **kw))
+    torch.cuda.synchronize()
+    assert (out.float() - out3.float()).abs().max().item() <= 4e-3 * max(1.0, out3.float().abs().max().item())
+
+
+def test_groupnorm_one_launch_refuses_what_does_not_fit(L):
+    """T * band / 8 beyond 16 vectors per thread, or an odd group size whose band would hold more than four groups: EINVAL with a message,
+    never a silent wrong launch; ops.gn_self_ok agrees with the library."""
+    from live2diff_amd import _lib
+    for (C, T) in ((1280, 4096), (1920, 400), (160, 64)):
+        assert not L.gn_self_ok(T, C, 32)
+        x = rnd(1, T, C, seed=1).to(DEV)
+        g = torch.ones(C, dtype=torch.float16, device=DEV)
+        out = torch.empty_like(x)
+        with pytest.raises(_lib.L2DError):
+            L.run(L.gn_apply(x, None, g, g, out, eps=1e-5, silu=False, B=1, T=T, C1=C, ld1=C, G=32, nchunk=0))
+
+
 @pytest.mark.parametrize("B,T,K,C,tile,splitk,choff2,Ccat", [
     (2, 4096, 320, 320, 1, 1, 0, 640),        # 128x128 tile, cpg 10 / 20: groups straddle the 128-channel tiles
     (2, 1024, 640, 640, 2, 1, 640, 1280),     # 64x64 tile; second consumer sees this tensor as the upper half of a concat

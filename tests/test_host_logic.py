@@ -347,6 +347,48 @@ def test_plain_k1280_linear_stays_on_igemm_where_the_chain_does_not_run(dry_run)
     assert sum(1 for o in ops_ if o.kind == _lib.OP_IGEMM and o.i[0] == 1 and o.i[13] == 2560 and o.i[1] == 1280 and o.i[14] == 320) == 10
 
 
+def test_one_launch_groupnorm_rule_agrees_with_the_library(dry_run):
+    """ops.gn_self_ok (which GroupNorms the plan gives to the one-launch form, norm.hip gn_self_kernel) must be exactly the set the C
+    library accepts for gn_apply with nchunk = 0 and no accumulator: checked through the library's validate-only mode over the SD widths,
+    their concats and pixel counts of tuned and untuned levels."""
+    from live2diff_amd import _lib, ops
+    n_ok = 0
+    for C in (64, 160, 320, 640, 960, 1280, 1920, 2560):
+        for T in (16, 36, 64, 100, 144, 256, 400, 576, 1024, 4096):
+            x = torch.zeros(1, T, C, dtype=torch.float16)
+            g = torch.ones(C, dtype=torch.float16)
+            op = ops.gn_apply(x, None, g, g, torch.empty_like(x), eps=1e-5, silu=True, B=1, T=T, C1=C, ld1=C, G=32, nchunk=0)
+            ok = True
+            try:
+                ops.run(op)
+            except _lib.L2DError as e:
+                ok = False
+                assert "one-launch form" in str(e)
+            assert ok == ops.gn_self_ok(T, C, 32), (C, T, ok)
+            n_ok += ok
+    assert 20 < n_ok < 70
+
+
+def test_untuned_resolution_uses_the_fallback_rules(dry_run):
+    """384 x 384 (48 x 48 latent, N = 2): no table holds its shapes.  The plan must take the chain kernel at 144 blocks, the one-launch
+    GroupNorm at the 12 x 12 / 6 x 6 levels (no gn_stats launch left but the ones that do not fit), and stay under 480 launches
+    (566 before round 6's fallback rules)."""
+    from live2diff_amd import _lib
+    from live2diff_amd.config import sd15_config
+    from live2diff_amd.unet_hip import HipStreamingUNet
+    from live2diff_amd.weights import unet_param_spec
+    cfg = sd15_config()
+    sd = {k: torch.zeros(shp, dtype=torch.float16) for k, shp in unet_param_spec(cfg).items()}
+    unet = HipStreamingUNet(sd, cfg, 48, 48, 2, device="cpu")
+    del sd
+    st = unet._plan("stream", unet.prepare_cache(2))
+    st.pl.run(stream=0)
+    summ = unet.plan_summary("stream")
+    kinds = summ["kinds"]
+    assert kinds.get(_lib.OP_ROWCHAIN, 0) == 30 and summ["gn_self_launches"] >= 38 and kinds.get(_lib.OP_GN_STATS, 0) <= 2
+    assert st.n_ops <= 480, st.n_ops
+
+
 def test_pipeline_mirror_keeps_the_reference_api_surface():
     """names the Python counterpart of `StreamAnimateDiffusionDepth` must preserve (reference
     pipeline_stream_animation_depth.py:24-666), checked on a CPU instance driven by a stand-in UNet callable -- the
