@@ -251,7 +251,7 @@ def rowchain_head(x, hout, out, *, M, C, wA, bA, wB, bB=None, passes=1, resA=Non
 ROWCHAIN_C = 320                # the width the chain kernel is instantiated for (SD-1.5 level 0)
 # M / 32 blocks.  Round 5 set 192 from the BASELINE configs (256+ blocks, or cfg-1's 32); round 6 measured the gap: 144 blocks (384 x 384,
 # N = 2) 7.70 -> 7.40 ms, 154 blocks (448 x 704, N = 1) 8.34 -> 7.98 ms, 100 blocks (320 x 320, N = 2) 7.09 -> 7.00 ms with the chain
-# (profiles/round6_v_*, round6_w_*); cfg-1 (32 blocks) keeps the separate launches
+# (profiles/round6_v_*, round6_w_*); cfg-1 (32 blocks) keeps the separate launches: 5.14 ms against 5.31 with the chain (round6_ab_*)
 ROWCHAIN_MIN_BLOCKS = int(os.environ.get("L2D_ROWCHAIN_MIN_BLOCKS", "96"))
 
 
