@@ -389,6 +389,29 @@ def test_untuned_resolution_uses_the_fallback_rules(dry_run):
     assert st.n_ops <= 480, st.n_ops
 
 
+def test_igemm_fallback_rule_follows_the_tuned_table():
+    """Round 6: the rule behind igemm_tuned.json (`ops._igemm_heuristic_r6`, what every shape outside cfg-2 runs on) is fitted to the table's
+    in-frame picks and must keep reproducing them -- (tile, split-K) of at least 50 of the 60 shapes (the round-1 rule: 30), every
+    few-token Linear / 8 x 8 conv among them, and always a schedule the launcher accepts (fused split-K <= 16, >= 2 BK64 steps per split)."""
+    import json
+
+    from live2diff_amd import ops
+    shapes = json.load(open(os.path.join(os.path.dirname(ops.__file__), "igemm_tuned.json")))["shapes"]
+    hit_new = hit_old = 0
+    for key, (tile, S, _v) in shapes.items():
+        taps, M, N, Kp, epi, batch = (int(v) for v in key.split(","))
+        t6, s6, v6 = ops._igemm_heuristic_r6(M, N, Kp, batch, epi)
+        t1, s1, _ = ops._igemm_heuristic_r1(M, N, Kp, batch, epi)
+        assert t6 in (1, 2) and 1 <= s6 <= ops.SPLITK_FUSED_MAX and Kp // 64 >= 2 * s6 and 0 <= v6 <= 10, key
+        hit_new += (t6, s6) == (tile, S)
+        hit_old += (t1, s1) == (tile, S)
+        if M <= 128 and N == 1280:
+            assert (t6, s6) == (tile, S), key                    # level 3 + mid of cfg-2: the launches the old rule lost most on
+    assert hit_new >= 50 and hit_old <= 32, (hit_new, hit_old)
+    # shapes no table holds: few tokens -> 64 x 64 tiles, K split towards ~240-480 blocks
+    assert ops._igemm_heuristic_r6(288, 1280, 1280, 1, 0)[:2] == (2, 2) and ops._igemm_heuristic_r6(72, 1280, 11520, 1, 0)[:2] == (2, 6)
+
+
 def test_pipeline_mirror_keeps_the_reference_api_surface():
     """names the Python counterpart of `StreamAnimateDiffusionDepth` must preserve (reference
     pipeline_stream_animation_depth.py:24-666), checked on a CPU instance driven by a stand-in UNet callable -- the
