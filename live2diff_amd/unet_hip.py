@@ -496,7 +496,10 @@ class HipStreamingUNet:
                     old_levels=[((self.h >> l) * (self.w >> l)) % 32 != 0 for l in range(nl)],
                     ws_skip=sorted(ops._WS_SKIP), ws_large=sorted(ops._WS_LARGE), ws_tokens=[self.N * (self.h >> l) * (self.w >> l) if self.ws_levels[l] else 0 for l in range(nl)],
                     cconv=os.environ.get("L2D_CCONV", "1"), rowgemm=os.environ.get("L2D_ROWGEMM", "1"), rowchain=os.environ.get("L2D_ROWCHAIN", "1"), rg_plain_max_k=os.environ.get("L2D_ROWGEMM_PLAIN_MAX_K", "640"),
-                    rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"))
+                    rg_ff1_max_k=os.environ.get("L2D_ROWGEMM_FF1_MAX_K", "1280"),
+                    # round 6: the fallback rules decide packed forms too (which layers take the weight-streaming form at token counts the
+                    # tuner never saw; from how many blocks a level packs the chain kernel's weights)
+                    ws_rule=os.environ.get("L2D_WSGEMM_RULE", "1"), rowchain_min_blocks=int(ops.ROWCHAIN_MIN_BLOCKS))
 
     @staticmethod
     def packed_cache_name(model_name: str, few_step_model_type: str, window_size: int, lora_dict: Optional[dict] = None,
